@@ -1,0 +1,730 @@
+// Blur operator A = ReflectionPad2d(R) + depthwise cross-correlation, and its
+// exact adjoint A^T = reflection-fold o full-correlation-transpose
+// (reference: util/img_utils.py:268-283, measurements.py:93-149).
+//
+// One workgroup (256 threads = 4 waves) owns a 64x64 output tile of one
+// (particle, channel) plane:
+//   stage A  HBM -> LDS: the tile plus a halo of R4 (= R rounded up to 4) as
+//            16-byte loads; in the fused DPS step the loader computes x0_hat
+//            from x_t/eps on the fly (S1), and writes x0_hat / sample / clamp
+//            gate for the tile interior, so x0_hat never makes a round trip;
+//   separable kernels (Gaussian): horizontal pass LDS->LDS, 8 outputs per
+//            thread from a register sliding window (taps live in SGPRs),
+//            then vertical pass LDS->registers, 4x4 outputs per thread;
+//   generic kernels (motion): list of non-zero taps, 16 outputs per thread;
+//   epilogue residual y - A x0 (+ per-tile sum of squares, deterministic), or for the
+//            adjoint the clamp gate and the -b * coef scaling into g_model_out.
+// Blocks are numbered so that the tiles of one plane share blockIdx % 8, i.e.
+// one XCD and its L2 (halo re-reads then hit L2, not HBM).
+#include "common.h"
+
+namespace dpsx {
+
+constexpr int TH = 64, TW = 64, NT = 256;
+
+struct BlurArgs {
+    // plain input / output
+    const float *x;       // [planes, h, w]            (fwd !POST, adjoint input u)
+    float *out;           // fwd: A x or residual r (may be null when RESID); adj !EPI: g
+    // fused S1 prologue (POST)
+    const float *x_t, *model_out, *noise;
+    float *x0_hat, *sample;
+    uint8_t *inside_w;
+    // residual epilogue (RESID)
+    const float *y;
+    int y_n;
+    float *partials;      // [planes * tiles]
+    // adjoint epilogue (EPI)
+    const float *norm_in; // [n] (finalized by the forward half of the step)
+    const uint8_t *inside_r;
+    float *g_model_out;
+    float scale;
+    int power;
+    // geometry
+    int c, h, w, tiles_x, tiles_y, planes;
+    Coefs k;
+    // generic taps
+    const int *tap_dy, *tap_dx;
+    const float *tap_w;
+    int nnz;
+};
+
+__device__ __forceinline__ bool block_to_tile(const BlurArgs &a, int &plane, int &ty, int &tx)
+{
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, k = b >> 3;
+    plane = (k / tiles) * 8 + xcd;
+    const int t = k % tiles;
+    ty = t / a.tiles_x;
+    tx = t % a.tiles_x;
+    return plane < a.planes;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------- stage A
+// Fill s_in[RH][SW] with the region whose top-left image coordinate is (gy0, gx0).
+// REFLECT: forward operator (reflection padding); else zero extension (adjoint).
+template <bool POST, bool REFLECT, bool VEC>
+__device__ __forceinline__ void load_region(float *s_in, const int SW, const int RH, const int RW,
+                                            const int gy0, const int gx0, const int h0, const int w0,
+                                            const BlurArgs &a, const int plane)
+{
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int n = plane / a.c, ch = plane % a.c;
+    const float *src = nullptr, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+    if constexpr (POST) {
+        src = a.x_t + (int64_t)plane * hw;
+        eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * hw;
+        vv = eps + (int64_t)a.c * hw;
+        zz = a.noise + (int64_t)plane * hw;
+    } else {
+        src = a.x + (int64_t)plane * hw;
+    }
+    constexpr int U = VEC ? 4 : 1;
+    const int RWu = RW / U;
+    for (int u = threadIdx.x; u < RH * RWu; u += NT) {
+        const int rr = u / RWu, cu = u - rr * RWu;
+        const int gy = gy0 + rr, gx = gx0 + cu * U;
+        float val[U];
+        float ev[U];
+        bool rowok = true;
+        int sy = gy;
+        if constexpr (REFLECT) sy = clampi(reflect_idx(gy, h), 0, h - 1);
+        else rowok = gy >= 0 && gy < h;
+        const bool fast = VEC && gx >= 0 && gx + U - 1 < w;
+        if (!rowok) {
+#pragma unroll
+            for (int e = 0; e < U; ++e) val[e] = 0.0f;
+        } else if (fast) {
+            if constexpr (VEC) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)sy * w + gx);
+                val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+                if constexpr (POST) {
+                    const float4 q = *reinterpret_cast<const float4 *>(eps + (int64_t)sy * w + gx);
+                    ev[0] = q.x; ev[1] = q.y; ev[2] = q.z; ev[3] = q.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                int sx = gx + e;
+                bool ok = true;
+                if constexpr (REFLECT) sx = clampi(reflect_idx(sx, w), 0, w - 1);
+                else ok = sx >= 0 && sx < w;
+                val[e] = ok ? src[(int64_t)sy * w + sx] : 0.0f;
+                if constexpr (POST) ev[e] = eps[(int64_t)sy * w + sx];
+            }
+        }
+        if constexpr (POST) {
+            bool ins[U];
+            float xin[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                xin[e] = val[e];
+                val[e] = post_x0(xin[e], ev[e], a.k, ins[e]);
+            }
+            // tile interior: emit x0_hat, sample and the clamp gate
+            const bool interior = gy >= h0 && gy < h0 + TH && gy < h && gx >= w0 && gx < w0 + TW && gx < w;
+            if (interior) {
+                const int64_t o = (int64_t)gy * w + gx;
+                float sm[U];
+                if (fast || !VEC) {
+                    float vq[U], zq[U];
+                    if constexpr (VEC) {
+                        float4 t4 = make_float4(0, 0, 0, 0), z4 = t4;
+                        if (a.k.add_noise) {
+                            t4 = *reinterpret_cast<const float4 *>(vv + o);
+                            z4 = *reinterpret_cast<const float4 *>(zz + o);
+                        }
+                        vq[0] = t4.x; vq[1] = t4.y; vq[2] = t4.z; vq[3] = t4.w;
+                        zq[0] = z4.x; zq[1] = z4.y; zq[2] = z4.z; zq[3] = z4.w;
+                    } else {
+                        vq[0] = a.k.add_noise ? vv[o] : 0.0f;
+                        zq[0] = a.k.add_noise ? zz[o] : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < U; ++e) sm[e] = post_sample(xin[e], val[e], vq[e], zq[e], a.k);
+                    float *x0p = a.x0_hat + (int64_t)plane * hw + o;
+                    float *smp = a.sample + (int64_t)plane * hw + o;
+                    uint8_t *inp = a.inside_w + (int64_t)plane * hw + o;
+                    if constexpr (VEC) {
+                        *reinterpret_cast<float4 *>(x0p) = make_float4(val[0], val[1], val[2], val[3]);
+                        *reinterpret_cast<float4 *>(smp) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+                        *reinterpret_cast<uchar4 *>(inp) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
+                    } else {
+                        *x0p = val[0];
+                        *smp = sm[0];
+                        *inp = ins[0];
+                    }
+                }
+            }
+        }
+        float *dst = s_in + rr * SW + cu * U;
+        if constexpr (VEC) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+        else dst[0] = val[0];
+    }
+}
+
+// ---------------------------------------------------------------- epilogues
+// residual of up to 4 consecutive columns of one output row; returns their sum of squares
+template <bool VEC4>
+__device__ __forceinline__ float resid_epilogue(const BlurArgs &a, int plane, int oy, int ox, const float *acc4,
+                                                int count = 4)
+{
+    const int64_t hw = (int64_t)a.h * a.w;
+    float ss = 0.0f;
+    if (oy >= a.h) return 0.0f;
+    const int n = plane / a.c, ch = plane % a.c;
+    const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + (int64_t)oy * a.w;
+    float *rp = a.out ? a.out + (int64_t)plane * hw + (int64_t)oy * a.w : nullptr;
+    if (VEC4 && count == 4 && ox + 3 < a.w) {
+        const float4 yv = *reinterpret_cast<const float4 *>(yp + ox);
+        float4 r;
+        r.x = yv.x - acc4[0]; r.y = yv.y - acc4[1]; r.z = yv.z - acc4[2]; r.w = yv.w - acc4[3];
+        if (rp) *reinterpret_cast<float4 *>(rp + ox) = r;
+        ss = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    } else {
+        for (int e = 0; e < count; ++e)
+            if (ox + e < a.w) {
+                const float r = yp[ox + e] - acc4[e];
+                if (rp) rp[ox + e] = r;
+                ss += r * r;
+            }
+    }
+    return ss;
+}
+
+__device__ __forceinline__ float norm_coef_dev(float nv, float gn, int power)
+{
+    return power == 2 ? -2.0f * gn : (nv == 0.0f ? 0.0f : -gn / nv);
+}
+
+// plain output (epi == false) or clamp gate + -b*coef scaling into g_model_out[:, :c]
+template <bool VEC4>
+__device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int oy, int ox, const float *acc4,
+                                             float coef, bool epi, int count = 4)
+{
+    if (oy >= a.h) return;
+    const int64_t hw = (int64_t)a.h * a.w;
+    const int64_t o = (int64_t)oy * a.w + ox;
+    if (!epi) {
+        float *gp = a.out + (int64_t)plane * hw + o;
+        if (VEC4 && count == 4 && ox + 3 < a.w)
+            *reinterpret_cast<float4 *>(gp) = make_float4(acc4[0], acc4[1], acc4[2], acc4[3]);
+        else
+            for (int e = 0; e < count; ++e)
+                if (ox + e < a.w) gp[e] = acc4[e];
+        return;
+    }
+    const int n = plane / a.c, ch = plane % a.c;
+    const uint8_t *ip = a.inside_r + (int64_t)plane * hw + o;
+    float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
+    const float mb = -a.k.b;
+    if (VEC4 && count == 4 && ox + 3 < a.w) {
+        const uchar4 in = *reinterpret_cast<const uchar4 *>(ip);
+        float4 g;
+        g.x = in.x ? mb * (coef * acc4[0]) : 0.0f;
+        g.y = in.y ? mb * (coef * acc4[1]) : 0.0f;
+        g.z = in.z ? mb * (coef * acc4[2]) : 0.0f;
+        g.w = in.w ? mb * (coef * acc4[3]) : 0.0f;
+        *reinterpret_cast<float4 *>(gp) = g;
+    } else {
+        for (int e = 0; e < count; ++e)
+            if (ox + e < a.w) gp[e] = ip[e] ? mb * (coef * acc4[e]) : 0.0f;
+    }
+}
+
+// =====================================================================
+// Separable path.  RR = padded radius (multiple of 4, <= 32); taps centred at index RR.
+// LDS: s_in[RH][SW] | s_tmp[RH][TW] | 256 floats of scratch
+// =====================================================================
+template <int RR>
+__device__ __forceinline__ void hpass_main(const float *s_in, float *s_tmp, const int SW, const int RH,
+                                           const float (&taps)[2 * kMaxRadius + 1])
+{
+    // items: (row, group of 8 outputs); window = 8 + 2*RR floats read as float4
+    constexpr int NG = TW / 8, NF = (8 + 2 * RR) / 4;
+    for (int it = threadIdx.x; it < RH * NG; it += NT) {
+        const int rr = it / NG, g = it - rr * NG;
+        const float *row = s_in + rr * SW + g * 8;
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(row + 4 * j);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const int d = 4 * j + e - o;  // tap index (0 .. 2RR)
+                    if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], v[e], acc[o]);
+                }
+            }
+        }
+        float *dst = s_tmp + rr * TW + g * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+template <int RR>
+__device__ __forceinline__ void vpass_main(const float *s_tmp, float (&acc)[4][4], const int rg, const int cg,
+                                           const float (&taps)[2 * kMaxRadius + 1])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4 + 2 * RR; ++j) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(s_tmp + (4 * rg + j) * TW + 4 * cg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = j - i;
+            if (d >= 0 && d <= 2 * RR) {
+                acc[i][0] = fmaf(taps[d], v4.x, acc[i][0]);
+                acc[i][1] = fmaf(taps[d], v4.y, acc[i][1]);
+                acc[i][2] = fmaf(taps[d], v4.z, acc[i][2]);
+                acc[i][3] = fmaf(taps[d], v4.w, acc[i][3]);
+            }
+        }
+    }
+}
+
+template <int R4, bool POST, bool RESID, bool VEC>
+__global__ __launch_bounds__(NT) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
+{
+    constexpr int RR = 4 * R4, RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds, *s_tmp = lds + RH * SW, *s_red = s_tmp + RH * TW;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    __syncthreads();
+    hpass_main<RR>(s_in, s_tmp, SW, RH, taps.h);
+    __syncthreads();
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float acc[4][4];
+    vpass_main<RR>(s_tmp, acc, rg, cg, taps.v);
+    const int ox = w0 + 4 * cg;
+    float ss = 0.0f;
+    if (ox < a.w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = h0 + 4 * rg + i;
+            if constexpr (RESID) ss += resid_epilogue<VEC>(a, plane, oy, ox, acc[i]);
+            else out_epilogue<VEC>(a, plane, oy, ox, acc[i], 0.0f, false);
+        }
+    }
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+    }
+}
+
+// Padded positions other than i itself that ReflectionPad maps onto image index i
+// (axis length n, pad R < n): -i for 1 <= i <= R, and 2(n-1)-i for n-1-R <= i <= n-2.
+__device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
+{
+    int cnt = 0;
+    if (i >= 1 && i <= R) p[cnt++] = -i;
+    if (i <= n - 2 && i >= n - 1 - R) p[cnt++] = 2 * (n - 1) - i;
+    return cnt;
+}
+
+template <int R4, bool EPI, bool VEC>
+__global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps /* already flipped */, int radius)
+{
+    constexpr int RR = 4 * R4, RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds, *s_tmp = lds + RH * SW, *s_th = s_tmp + RH * TW, *s_tv = s_th + 80;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    float coef = 0.0f;
+    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
+    for (int i = threadIdx.x; i <= 2 * RR; i += NT) {
+        s_th[i] = taps.h[i];
+        s_tv[i] = taps.v[i];
+    }
+    load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    __syncthreads();
+    // T[rr][c] = sum_d hflip[d] * u_z[row][c + d - RR]
+    hpass_main<RR>(s_in, s_tmp, SW, RH, taps.h);
+    __syncthreads();
+    // horizontal fold: columns 1..R also receive G[-j]; columns w-1-R..w-2 receive G[2(w-1)-j]
+    const bool wborder = (w0 <= radius) || (w0 + TW >= a.w - 1 - radius);
+    if (wborder) {
+        for (int it = threadIdx.x; it < RH * 2 * radius; it += NT) {
+            const int rr = it / (2 * radius), q = it - rr * 2 * radius;
+            const bool left = q < radius;
+            const int j = left ? 1 + q : a.w - 2 - (q - radius);
+            if (j < w0 || j >= w0 + TW || j < 0 || j >= a.w) continue;
+            if (!left && j >= 1 && j <= radius) continue;  // already owned by the left list
+            int src[2];
+            const int cnt = fold_sources(j, a.w, radius, src);
+            float add = 0.0f;
+            for (int s = 0; s < cnt; ++s) {
+                // G[p] = sum_d hflip[d] * u_z[p + d - RR]; region column = p - w0 + d
+                const int base = src[s] - w0;
+                for (int d = RR - radius; d <= RR + radius; ++d) {
+                    const int col = base + d;
+                    if (col >= 0 && col < RW) add = fmaf(s_th[d], s_in[rr * SW + col], add);
+                }
+            }
+            s_tmp[rr * TW + (j - w0)] += add;  // one item per (row, column): no two threads share a word
+        }
+        __syncthreads();
+    }
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float acc[4][4];
+    vpass_main<RR>(s_tmp, acc, rg, cg, taps.v);
+    const bool hborder = (h0 <= radius) || (h0 + TH >= a.h - 1 - radius);
+    if (hborder) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = h0 + 4 * rg + i;
+            if (oy >= a.h) continue;
+            int src[2];
+            const int cnt = fold_sources(oy, a.h, radius, src);
+            for (int s = 0; s < cnt; ++s) {
+                const int base = src[s] - h0;  // region row = base + d
+                for (int d = RR - radius; d <= RR + radius; ++d) {
+                    const int row = base + d;
+                    if (row >= 0 && row < RH) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(s_tmp + row * TW + 4 * cg);
+                        const float t = s_tv[d];
+                        acc[i][0] = fmaf(t, v4.x, acc[i][0]);
+                        acc[i][1] = fmaf(t, v4.y, acc[i][1]);
+                        acc[i][2] = fmaf(t, v4.z, acc[i][2]);
+                        acc[i][3] = fmaf(t, v4.w, acc[i][3]);
+                    }
+                }
+            }
+        }
+    }
+    const int ox = w0 + 4 * cg;
+    if (ox < a.w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out_epilogue<VEC>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
+    }
+}
+
+// =====================================================================
+// Generic path: list of non-zero taps (dy, dx in [-R, R], weight), read through
+// wave-uniform scalar loads.  thread -> column tid % 64, rows (tid / 64) + 4*i, i < 16:
+// consecutive lanes read consecutive LDS words (conflict-free ds_read_b32).
+// LDS: s_in[RH][SW] | 256 floats of scratch
+// =====================================================================
+constexpr int GI = 16;  // outputs per thread
+
+template <bool POST, bool RESID, bool VEC>
+__global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
+{
+    const int RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds, *s_red = lds + RH * SW;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    __syncthreads();
+    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    float acc[GI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
+    const float *base = s_in + (r0 + RR) * SW + col + RR;
+    for (int t = 0; t < a.nnz; ++t) {
+        const float wgt = a.tap_w[t];
+        const float *p = base + a.tap_dy[t] * SW + a.tap_dx[t];
+#pragma unroll
+        for (int i = 0; i < GI; ++i) acc[i] = fmaf(wgt, p[4 * i * SW], acc[i]);
+    }
+    const int ox = w0 + col;
+    float ss = 0.0f;
+    if (ox < a.w) {
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int oy = h0 + r0 + 4 * i;
+            if constexpr (RESID) ss += resid_epilogue<false>(a, plane, oy, ox, &acc[i], 1);
+            else out_epilogue<false>(a, plane, oy, ox, &acc[i], 0.0f, false, 1);
+        }
+    }
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+    }
+}
+
+// adjoint: g[i][j] = sum_{p in {i} U fold(i)} sum_{q in {j} U fold(j)} sum_taps w * u_z[p - dy][q - dx]
+template <bool EPI, bool VEC>
+__global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int radius)
+{
+    const int RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    float coef = 0.0f;
+    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
+    load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    __syncthreads();
+    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    float acc[GI];
+#pragma unroll
+    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
+    // main term (p = i, q = j): always inside the region
+    const float *base = s_in + (r0 + RR) * SW + col + RR;
+    for (int t = 0; t < a.nnz; ++t) {
+        const float wgt = a.tap_w[t];
+        const float *p = base - a.tap_dy[t] * SW - a.tap_dx[t];
+#pragma unroll
+        for (int i = 0; i < GI; ++i) acc[i] = fmaf(wgt, p[4 * i * SW], acc[i]);
+    }
+    const bool border = (w0 <= radius) || (w0 + TW >= a.w - 1 - radius) || (h0 <= radius) ||
+                        (h0 + TH >= a.h - 1 - radius);
+    const int ox = w0 + col;
+    if (border && ox < a.w) {
+        int sx[2];
+        const int nx = fold_sources(ox, a.w, radius, sx);
+        const int qs[3] = {ox, sx[0], sx[1]};
+        for (int i = 0; i < GI; ++i) {
+            const int oy = h0 + r0 + 4 * i;
+            if (oy >= a.h) continue;
+            int sy[2];
+            const int ny = fold_sources(oy, a.h, radius, sy);
+            if (nx == 0 && ny == 0) continue;
+            const int ps[3] = {oy, sy[0], sy[1]};
+            float add = 0.0f;
+            for (int ip = 0; ip <= ny; ++ip)
+                for (int iq = 0; iq <= nx; ++iq) {
+                    if (ip == 0 && iq == 0) continue;  // main term done
+                    const int pr = ps[ip] - (h0 - RR), qc = qs[iq] - (w0 - RR);
+                    for (int t = 0; t < a.nnz; ++t) {
+                        const int row = pr - a.tap_dy[t], cc = qc - a.tap_dx[t];
+                        if (row >= 0 && row < RH && cc >= 0 && cc < RW)
+                            add = fmaf(a.tap_w[t], s_in[row * SW + cc], add);
+                    }
+                }
+            acc[i] += add;
+        }
+    }
+    if (ox < a.w) {
+#pragma unroll
+        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + 4 * i, ox, &acc[i], coef, EPI, 1);
+    }
+}
+
+// =====================================================================
+// host dispatch
+// =====================================================================
+constexpr size_t kScratchBytes = 1024;
+static inline size_t sep_lds_bytes(int rr)
+{
+    return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4) + (TH + 2 * rr) * TW) * 4 + kScratchBytes;
+}
+static inline size_t taps_lds_bytes(int rr) { return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4)) * 4 + kScratchBytes; }
+
+static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int64_t w)
+{
+    a.c = (int)c; a.h = (int)h; a.w = (int)w; a.planes = (int)planes;
+    a.tiles_x = (int)((w + TW - 1) / TW);
+    a.tiles_y = (int)((h + TH - 1) / TH);
+}
+
+static inline unsigned grid_blocks(const BlurArgs &a)
+{
+    const int groups = (a.planes + 7) / 8;
+    return (unsigned)(groups * 8 * a.tiles_x * a.tiles_y);
+}
+
+int64_t blur_parts_per_particle(const dpsx_op *, int64_t c, int64_t h, int64_t w)
+{
+    return c * ((h + TH - 1) / TH) * ((w + TW - 1) / TW);
+}
+
+// dynamic LDS above 64 KiB needs the attribute once per kernel symbol
+template <typename K>
+static int allow_lds(K kernel, size_t bytes, bool &done)
+{
+    if (!done) {
+        DPSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        done = true;
+    }
+    (void)bytes;
+    return DPSX_OK;
+}
+
+#define DPSX_LAUNCH(KERNEL, GRID, LDS, STREAM, ...)                      \
+    do {                                                                  \
+        static bool s_attr_done = false;                                  \
+        int rc_ = allow_lds(&KERNEL, LDS, s_attr_done);                   \
+        if (rc_ != DPSX_OK) return rc_;                                   \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(NT), LDS, STREAM, __VA_ARGS__); \
+        return check_launch();                                            \
+    } while (0)
+
+template <int R4, bool POST, bool RESID>
+static int launch_sep_fwd(const BlurArgs &a, const SepTaps &t, bool vec, hipStream_t s)
+{
+    const size_t lds = sep_lds_bytes(4 * R4);
+    if (vec) DPSX_LAUNCH((k_blur_sep_fwd<R4, POST, RESID, true>), grid_blocks(a), lds, s, a, t);
+    DPSX_LAUNCH((k_blur_sep_fwd<R4, POST, RESID, false>), grid_blocks(a), lds, s, a, t);
+}
+
+template <bool POST, bool RESID>
+static int dispatch_sep_fwd(const dpsx_op *op, const BlurArgs &a, bool vec, hipStream_t s)
+{
+    switch (op->radius4 / 4) {
+    case 1: return launch_sep_fwd<1, POST, RESID>(a, op->sep, vec, s);
+    case 2: return launch_sep_fwd<2, POST, RESID>(a, op->sep, vec, s);
+    case 3: return launch_sep_fwd<3, POST, RESID>(a, op->sep, vec, s);
+    case 4: return launch_sep_fwd<4, POST, RESID>(a, op->sep, vec, s);
+    case 5: return launch_sep_fwd<5, POST, RESID>(a, op->sep, vec, s);
+    case 6: return launch_sep_fwd<6, POST, RESID>(a, op->sep, vec, s);
+    case 7: return launch_sep_fwd<7, POST, RESID>(a, op->sep, vec, s);
+    case 8: return launch_sep_fwd<8, POST, RESID>(a, op->sep, vec, s);
+    }
+    return DPSX_EUNSUPPORTED;
+}
+
+template <int R4, bool EPI>
+static int launch_sep_adj(const BlurArgs &a, const SepTaps &t, int radius, bool vec, hipStream_t s)
+{
+    const size_t lds = sep_lds_bytes(4 * R4);
+    if (vec) DPSX_LAUNCH((k_blur_sep_adj<R4, EPI, true>), grid_blocks(a), lds, s, a, t, radius);
+    DPSX_LAUNCH((k_blur_sep_adj<R4, EPI, false>), grid_blocks(a), lds, s, a, t, radius);
+}
+
+template <bool EPI>
+static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, bool vec, hipStream_t s)
+{
+    SepTaps f{};  // adjoint of a correlation = correlation with the reversed taps
+    const int rr = op->radius4;
+    for (int i = 0; i <= 2 * rr; ++i) {
+        f.h[i] = op->sep.h[2 * rr - i];
+        f.v[i] = op->sep.v[2 * rr - i];
+    }
+    switch (rr / 4) {
+    case 1: return launch_sep_adj<1, EPI>(a, f, op->reach, vec, s);
+    case 2: return launch_sep_adj<2, EPI>(a, f, op->reach, vec, s);
+    case 3: return launch_sep_adj<3, EPI>(a, f, op->reach, vec, s);
+    case 4: return launch_sep_adj<4, EPI>(a, f, op->reach, vec, s);
+    case 5: return launch_sep_adj<5, EPI>(a, f, op->reach, vec, s);
+    case 6: return launch_sep_adj<6, EPI>(a, f, op->reach, vec, s);
+    case 7: return launch_sep_adj<7, EPI>(a, f, op->reach, vec, s);
+    case 8: return launch_sep_adj<8, EPI>(a, f, op->reach, vec, s);
+    }
+    return DPSX_EUNSUPPORTED;
+}
+
+static void set_taps(const dpsx_op *op, BlurArgs &a)
+{
+    a.tap_dy = op->d_tap_dy; a.tap_dx = op->d_tap_dx; a.tap_w = op->d_tap_w; a.nnz = op->nnz;
+}
+
+template <bool POST, bool RESID>
+static int launch_taps_fwd(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t s)
+{
+    set_taps(op, a);
+    const size_t lds = taps_lds_bytes(op->radius4);
+    if (vec) DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, true>), grid_blocks(a), lds, s, a, op->radius4);
+    DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, false>), grid_blocks(a), lds, s, a, op->radius4);
+}
+
+template <bool EPI>
+static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t s)
+{
+    set_taps(op, a);
+    const size_t lds = taps_lds_bytes(op->radius4);
+    if (vec) DPSX_LAUNCH((k_blur_taps_adj<EPI, true>), grid_blocks(a), lds, s, a, op->radius4, op->reach);
+    DPSX_LAUNCH((k_blur_taps_adj<EPI, false>), grid_blocks(a), lds, s, a, op->radius4, op->reach);
+}
+
+static bool geometry_ok(const dpsx_op *op, int64_t h, int64_t w)
+{
+    // ReflectionPad2d requires pad < dim (torch raises otherwise)
+    return h > op->radius && w > op->radius && h < (1 << 15) && w < (1 << 15);
+}
+
+static bool vec_ok(int64_t h, int64_t w, std::initializer_list<const void *> ptrs)
+{
+    if (w % 4 != 0 || (h * w) % 4 != 0) return false;
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+int blur_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, int64_t h, int64_t w, hipStream_t s)
+{
+    if (!geometry_ok(op, h, w)) return DPSX_EINVAL;
+    if (planes == 0) return DPSX_OK;
+    BlurArgs a{};
+    a.x = x; a.out = y;
+    fill_geometry(a, planes, 1, h, w);
+    const bool vec = vec_ok(h, w, {x, y});
+    return op->kind == OP_SEP ? dispatch_sep_fwd<false, false>(op, a, vec, s)
+                              : launch_taps_fwd<false, false>(op, a, vec, s);
+}
+
+int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, hipStream_t s)
+{
+    if (!geometry_ok(op, h, w)) return DPSX_EINVAL;
+    if (planes == 0) return DPSX_OK;
+    BlurArgs a{};
+    a.x = u; a.out = g;
+    fill_geometry(a, planes, 1, h, w);
+    const bool vec = vec_ok(h, w, {u, g});
+    return op->kind == OP_SEP ? dispatch_sep_adj<false>(op, a, vec, s) : launch_taps_adj<false>(op, a, vec, s);
+}
+
+int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
+{
+    if (!geometry_ok(op, f.h, f.w)) return DPSX_EINVAL;
+    if (f.n == 0) return DPSX_OK;
+    BlurArgs a{};
+    a.x_t = f.x_t; a.model_out = f.model_out; a.noise = f.noise;
+    a.x0_hat = f.x0_hat; a.sample = f.sample; a.inside_w = f.inside;
+    a.y = f.y; a.y_n = (int)f.y_n; a.out = f.resid; a.partials = f.partials;
+    a.k = f.k;
+    fill_geometry(a, f.n * f.c, f.c, f.h, f.w);
+    const bool vec = vec_ok(f.h, f.w, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.y, f.resid}) &&
+                     (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
+    return op->kind == OP_SEP ? dispatch_sep_fwd<true, true>(op, a, vec, s) : launch_taps_fwd<true, true>(op, a, vec, s);
+}
+
+int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
+{
+    if (!geometry_ok(op, b.h, b.w)) return DPSX_EINVAL;
+    if (b.n == 0) return DPSX_OK;
+    BlurArgs a{};
+    a.x = b.resid;
+    a.norm_in = b.norm;
+    a.inside_r = b.inside; a.g_model_out = b.g_model_out; a.scale = b.scale; a.power = b.power;
+    a.k = b.k;
+    fill_geometry(a, b.n * b.c, b.c, b.h, b.w);
+    const bool vec = vec_ok(b.h, b.w, {b.resid, b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
+    return op->kind == OP_SEP ? dispatch_sep_adj<true>(op, a, vec, s) : launch_taps_adj<true>(op, a, vec, s);
+}
+
+int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,
+               int64_t c, int64_t h, int64_t w, hipStream_t s)
+{
+    if (!geometry_ok(op, h, w)) return DPSX_EINVAL;
+    if (n == 0) return DPSX_OK;
+    BlurArgs a{};
+    a.x = x; a.y = y; a.y_n = (int)y_n; a.out = nullptr; a.partials = partials;
+    fill_geometry(a, n * c, c, h, w);
+    const bool vec = vec_ok(h, w, {x, y});
+    return op->kind == OP_SEP ? dispatch_sep_fwd<false, true>(op, a, vec, s) : launch_taps_fwd<false, true>(op, a, vec, s);
+}
+
+}  // namespace dpsx

@@ -1,0 +1,222 @@
+// dpsx internal helpers (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dpsx.h"
+
+namespace dpsx {
+
+constexpr int kWave = 64;
+
+// -------------------------------------------------------------------- errors
+void set_last_hip_error(hipError_t e);
+
+inline int check_launch()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return DPSX_ELAUNCH;
+    }
+    return DPSX_OK;
+}
+
+#define DPSX_HIP_TRY(expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) {                              \
+            ::dpsx::set_last_hip_error(_e);                  \
+            return _e == hipErrorOutOfMemory ? DPSX_ENOMEM : DPSX_ELAUNCH; \
+        }                                                    \
+    } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// -------------------------------------------------------------------- S1 point math
+// Reference op order, one rounding per ATen op (no FMA contraction), so the
+// element-wise chain is bit-identical to torch eager:
+//   posterior_mean_variance.py:120-123 (x0 from eps), :43-44 (clamp),
+//   :116-118 (mean), :239-240 (log-variance), gaussian_diffusion.py:472-474.
+struct Coefs {
+    float a, b, c1, c2, min_log, max_log;
+    int add_noise;
+};
+
+inline Coefs to_coefs(const dpsx_coefs *c)
+{
+    return Coefs{c->a, c->b, c->c1, c->c2, c->min_log, c->max_log, c->add_noise};
+}
+
+__device__ __forceinline__ float post_x0(float x, float e, const Coefs &c, bool &inside)
+{
+    float pre = __fsub_rn(__fmul_rn(c.a, x), __fmul_rn(c.b, e));
+    inside = (pre >= -1.0f) && (pre <= 1.0f);
+    return pre < -1.0f ? -1.0f : (pre > 1.0f ? 1.0f : pre);
+}
+
+__device__ __forceinline__ float post_logvar(float v, const Coefs &c)
+{
+    float frac = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);
+    return __fadd_rn(__fmul_rn(frac, c.max_log), __fmul_rn(__fsub_rn(1.0f, frac), c.min_log));
+}
+
+__device__ __forceinline__ float post_sample(float x, float x0, float v, float z, const Coefs &c)
+{
+    float mean = __fadd_rn(__fmul_rn(c.c1, x0), __fmul_rn(c.c2, x));
+    if (!c.add_noise) return mean;
+    float sd = expf(__fmul_rn(0.5f, post_logvar(v, c)));
+    return __fadd_rn(mean, __fmul_rn(sd, z));
+}
+
+// -------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// Deterministic block sum (fixed shuffle tree, waves added in index order).
+// Result valid in thread 0.  `scratch` holds >= blockDim.x/64 floats.
+__device__ __forceinline__ float block_sum(float v, float *scratch)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    float t = 0.0f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+// ReflectionPad2d index map (no edge repeat); valid while |overhang| < n.
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+}  // namespace dpsx
+
+// -------------------------------------------------------------------- op object
+enum { OP_TAPS = 0, OP_SEP = 1, OP_RESIZE = 2, OP_MASK = 3, OP_IDENT = 4, OP_PHASE = 5 };
+
+constexpr int kMaxRadius = 32;  // kernel side <= 65
+
+struct SepTaps {  // passed by value -> SGPRs
+    float h[2 * kMaxRadius + 1];
+    float v[2 * kMaxRadius + 1];
+};
+
+struct dpsx_op {
+    int kind = OP_IDENT;
+    // ---- blur
+    int ks = 0, radius = 0;               // radius = ks/2 = the reflection pad
+    int reach = 0, radius4 = 0;           // reach: largest |offset| of a non-zero tap; radius4: reach rounded up to 4
+    SepTaps sep{};                        // centred at index radius4 (zero padded)
+    int nnz = 0;
+    int *d_tap_dy = nullptr, *d_tap_dx = nullptr;  // sparse non-zero taps, row-major order
+    float *d_tap_w = nullptr;
+    // ---- resize
+    int64_t in_h = 0, in_w = 0, out_h = 0, out_w = 0, taps_h = 0, taps_w = 0;
+    float *d_w_h = nullptr;  // resize.hip keeps its table owner (ResizeHost*) here
+    // ---- mask
+    const float *mask = nullptr;
+    // ---- phase
+    int64_t pr_h = 0, pr_pad = 0, pr_planes = 0;
+    void *fft_plan = nullptr;  // hipfftHandle stored as integer
+    bool has_plan = false;
+};
+
+// kernels implemented across the .hip files (all enqueue on `s`, return a DPSX_* code)
+namespace dpsx {
+
+struct StepFwdArgs {
+    const float *x_t, *model_out, *noise, *y;
+    int64_t y_n;
+    float *x0_hat, *sample;
+    uint8_t *inside;
+    float *resid;
+    float *partials;  // [n * parts_per_particle] sums of squares, finalized into norm by the caller
+    int64_t n, c, h, w;
+    Coefs k;
+};
+
+struct StepBwdArgs {
+    const float *resid, *norm;
+    const uint8_t *inside;
+    const float *x0_hat, *y;
+    int64_t y_n;
+    float scale;
+    int power;
+    float *g_model_out;
+    int64_t n, c, h, w;
+    Coefs k;
+};
+
+// blur.hip
+int blur_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, int64_t h, int64_t w, hipStream_t s);
+int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, hipStream_t s);
+int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &a, hipStream_t s);
+int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
+int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
+               int64_t n, int64_t c, int64_t h, int64_t w, hipStream_t s);
+int64_t blur_parts_per_particle(const dpsx_op *op, int64_t c, int64_t h, int64_t w);
+
+// resize.hip
+int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float *w_w, const int64_t *i_w);
+void resize_destroy(dpsx_op *op);
+int64_t resize_parts_per_particle(const dpsx_op *op, int64_t c);
+int resize_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, hipStream_t s);
+int resize_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, hipStream_t s);
+int resize_step_fwd(const dpsx_op *op, const StepFwdArgs &a, hipStream_t s);
+int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
+int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
+                 int64_t n, int64_t c, hipStream_t s);
+
+// elementwise.hip
+int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, float *sample, uint8_t *inside,
+                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const float *mo, const float *z,
+                  float *g_x, float *g_mo, int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_t hw, hipStream_t s);
+// sums of squares of (y - ax) per particle in `parts` chunks -> partials[n*parts]; r optional
+int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials,
+                      int64_t n, int64_t m, int parts, hipStream_t s);
+int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipStream_t s);
+int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, float *g_ax,
+             int64_t n, int64_t m, hipStream_t s);
+// g_model_out[:, :c] = -b * (inside ? coef_p * g_x0 : 0),  g_x0 = A^T r
+int clamp_scale_to_eps(const float *g_x0, const float *norm, const uint8_t *inside, float scale, int power,
+                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+int step_update(const float *sample, const float *g_mo, const float *g_unet, float *x_next,
+                int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+int plain_update(const float *sample, const float *ga, const float *gb, float *out, int64_t count, hipStream_t s);
+int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &a, int parts, hipStream_t s);
+int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
+int argmin_f32(const float *v, int64_t n, int64_t *idx, hipStream_t s);
+int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
+               bool replicate, hipStream_t s);
+
+// phase.hip
+int phase_create(dpsx_op *op);
+void phase_destroy(dpsx_op *op);
+int64_t phase_workspace_bytes(const dpsx_op *op, int64_t planes);
+// amp = |F(pad(x))| ; spec (optional) receives the centred complex spectrum, interleaved re/im
+int phase_forward(dpsx_op *op, const float *x, float *amp, float *spec, int64_t planes,
+                  void *ws, int64_t ws_bytes, hipStream_t s);
+// g = Re crop F^H (u * z/|z|), z = spectrum at x (recomputed)
+int phase_adjoint(dpsx_op *op, const float *u, const float *x, float *g, int64_t planes,
+                  void *ws, int64_t ws_bytes, hipStream_t s);
+// fused step halves: fwd leaves w = (y-|z|) z/|z| (complex) in resid_c and the sums of squares in partials;
+// bwd turns resid_c into g_x0 = Re crop F^H w (unit cotangent) -- caller applies coef / clamp / -b
+int phase_step_fwd(dpsx_op *op, const float *x0_hat, const float *y, int64_t y_n, float *resid_c,
+                   float *partials, int64_t n, int64_t c, hipStream_t s);
+int phase_step_bwd(dpsx_op *op, float *resid_c, float *g_x0, int64_t planes, hipStream_t s);
+int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c);
+
+}  // namespace dpsx

@@ -1,0 +1,441 @@
+// Element-wise / reduction kernels of the DPS step (HBM-bound; 16 B per lane).
+//
+// Layout: particles are the outer dimension; one particle = chw contiguous
+// fp32; model_out holds 2*chw per particle (eps | v).  Fast paths need
+// chw % 4 == 0 and 16-byte aligned bases (torch allocations are), otherwise a
+// scalar kernel with identical arithmetic runs.
+#include "common.h"
+
+namespace dpsx {
+
+constexpr int kThreads = 256;
+
+static inline dim3 grid_for(int64_t work_per_particle, int64_t n)
+{
+    int64_t bx = (work_per_particle + kThreads - 1) / kThreads;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)n, 1);
+}
+
+// ===================================================================== S1 forward
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_posterior_fwd(const float *__restrict__ x,
+                                                            const float *__restrict__ mo,
+                                                            const float *__restrict__ z,
+                                                            float *__restrict__ x0o, float *__restrict__ so,
+                                                            uint8_t *__restrict__ ins, int64_t chw, Coefs k)
+{
+    const int64_t p = blockIdx.y;
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= chw) return;
+    const float *xp = x + p * chw + i, *ep = mo + p * 2 * chw + i, *vp = ep + chw;
+    const int64_t o = p * chw + i;
+    if constexpr (VEC) {
+        const float4 xv = *reinterpret_cast<const float4 *>(xp);
+        const float4 ev = *reinterpret_cast<const float4 *>(ep);
+        float4 vv = make_float4(0, 0, 0, 0), zv = vv;
+        if (k.add_noise) {
+            vv = *reinterpret_cast<const float4 *>(vp);
+            zv = *reinterpret_cast<const float4 *>(z + o);
+        }
+        bool b0, b1, b2, b3;
+        float4 x0, sm;
+        x0.x = post_x0(xv.x, ev.x, k, b0);
+        x0.y = post_x0(xv.y, ev.y, k, b1);
+        x0.z = post_x0(xv.z, ev.z, k, b2);
+        x0.w = post_x0(xv.w, ev.w, k, b3);
+        sm.x = post_sample(xv.x, x0.x, vv.x, zv.x, k);
+        sm.y = post_sample(xv.y, x0.y, vv.y, zv.y, k);
+        sm.z = post_sample(xv.z, x0.z, vv.z, zv.z, k);
+        sm.w = post_sample(xv.w, x0.w, vv.w, zv.w, k);
+        if (x0o) *reinterpret_cast<float4 *>(x0o + o) = x0;
+        if (so) *reinterpret_cast<float4 *>(so + o) = sm;
+        if (ins) *reinterpret_cast<uchar4 *>(ins + o) = make_uchar4(b0, b1, b2, b3);
+    } else {
+        bool b;
+        float x0 = post_x0(*xp, *ep, k, b);
+        float sm = post_sample(*xp, x0, k.add_noise ? *vp : 0.f, k.add_noise ? z[o] : 0.f, k);
+        if (x0o) x0o[o] = x0;
+        if (so) so[o] = sm;
+        if (ins) ins[o] = b;
+    }
+}
+
+int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, float *sample, uint8_t *inside,
+                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
+{
+    if (n == 0 || chw == 0) return DPSX_OK;
+    const bool vec = chw % 4 == 0 && aligned16(x) && aligned16(mo) && aligned16(z) && aligned16(x0) &&
+                     aligned16(sample) && (reinterpret_cast<uintptr_t>(inside) & 3u) == 0;
+    if (vec)
+        k_posterior_fwd<true><<<grid_for(chw / 4, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k);
+    else
+        k_posterior_fwd<false><<<grid_for(chw, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k);
+    return check_launch();
+}
+
+// ===================================================================== S1 backward
+// g_pre = [pre in [-1,1]] * (g_x0 + c1 g_s);  g_x = a g_pre + c2 g_s;
+// g_eps = -b g_pre;  g_v = g_s * z * sd * (max_log - min_log) / 4
+__global__ __launch_bounds__(kThreads) void k_posterior_bwd(const float *__restrict__ g_x0,
+                                                            const float *__restrict__ g_s,
+                                                            const float *__restrict__ x,
+                                                            const float *__restrict__ mo,
+                                                            const float *__restrict__ z,
+                                                            float *__restrict__ g_x, float *__restrict__ g_mo,
+                                                            int64_t chw, Coefs k)
+{
+    const int64_t p = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= chw) return;
+    const int64_t o = p * chw + i, e = p * 2 * chw + i;
+    bool in;
+    (void)post_x0(x[o], mo[e], k, in);
+    const float gs = g_s ? g_s[o] : 0.0f;
+    const float g0 = (g_x0 ? g_x0[o] : 0.0f) + k.c1 * gs;
+    const float gp = in ? g0 : 0.0f;
+    g_x[o] = k.a * gp + k.c2 * gs;
+    g_mo[e] = -k.b * gp;
+    float gv = 0.0f;
+    if (k.add_noise && g_s) {
+        const float sd = expf(0.5f * post_logvar(mo[e + chw], k));
+        gv = gs * z[o] * sd * (0.25f * (k.max_log - k.min_log));
+    }
+    g_mo[e + chw] = gv;
+}
+
+int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const float *mo, const float *z,
+                  float *g_x, float *g_mo, int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
+{
+    if (n == 0 || chw == 0) return DPSX_OK;
+    k_posterior_bwd<<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, g_s, x, mo, z, g_x, g_mo, chw, k);
+    return check_launch();
+}
+
+// ===================================================================== inpainting mask
+__global__ __launch_bounds__(kThreads) void k_mask_mul(const float *__restrict__ x, const float *__restrict__ m,
+                                                       float *__restrict__ y, int64_t hw)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= hw) return;
+    const int64_t o = (int64_t)blockIdx.y * hw + i;
+    y[o] = __fmul_rn(x[o], m[i]);
+}
+
+int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_t hw, hipStream_t s)
+{
+    if (planes == 0 || hw == 0) return DPSX_OK;
+    k_mask_mul<<<grid_for(hw, planes), kThreads, 0, s>>>(x, mask, y, hw);
+    return check_launch();
+}
+
+// ===================================================================== residual + norm
+// grid (parts, n): block (q, p) reduces elements [q*chunk, (q+1)*chunk) of particle p.
+__global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__restrict__ y, int64_t y_n,
+                                                                const float *__restrict__ ax,
+                                                                float *__restrict__ r,
+                                                                float *__restrict__ partials, int64_t m,
+                                                                int64_t chunk)
+{
+    __shared__ float scratch[kThreads / kWave];
+    const int64_t p = blockIdx.y, q = blockIdx.x;
+    const float *yp = y + (y_n == 1 ? 0 : p) * m, *ap = ax + p * m;
+    const int64_t lo = q * chunk, hi = min(m, lo + chunk);
+    float acc = 0.0f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const float d = __fsub_rn(yp[i], ap[i]);
+        if (r) r[p * m + i] = d;
+        acc = fmaf(d, d, acc);
+    }
+    const float t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partials[p * gridDim.x + q] = t;
+}
+
+int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials, int64_t n,
+                      int64_t m, int parts, hipStream_t s)
+{
+    if (n == 0) return DPSX_OK;
+    const int64_t chunk = (m + parts - 1) / parts;
+    k_residual_partials<<<dim3(parts, (unsigned)n), kThreads, 0, s>>>(y, y_n, ax, r, partials, m, chunk);
+    return check_launch();
+}
+
+// one wave per particle; partial sums added in index order within a lane, then a fixed tree
+__global__ __launch_bounds__(kWave) void k_finalize_norm(const float *__restrict__ partials, int parts,
+                                                         float *__restrict__ norm)
+{
+    const int64_t p = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < parts; i += kWave) acc += (double)partials[p * parts + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+    if (threadIdx.x == 0) norm[p] = (float)sqrt(acc);
+}
+
+int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipStream_t s)
+{
+    if (n == 0) return DPSX_OK;
+    k_finalize_norm<<<(unsigned)n, kWave, 0, s>>>(partials, parts, norm);
+    return check_launch();
+}
+
+__device__ __forceinline__ float norm_coef(float nv, float gn, int power)
+{
+    // d(gn * norm^power)/d(ax) = -coef * r ;  torch yields 0 where norm == 0
+    return power == 2 ? -2.0f * gn : (nv == 0.0f ? 0.0f : -gn / nv);
+}
+
+__global__ __launch_bounds__(kThreads) void k_norm_bwd(const float *__restrict__ r, const float *__restrict__ norm,
+                                                       const float *__restrict__ g_norm, int power,
+                                                       float *__restrict__ g_ax, int64_t m)
+{
+    const int64_t p = blockIdx.y, i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    g_ax[p * m + i] = norm_coef(norm[p], g_norm[p], power) * r[p * m + i];
+}
+
+int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, float *g_ax, int64_t n,
+             int64_t m, hipStream_t s)
+{
+    if (n == 0 || m == 0) return DPSX_OK;
+    k_norm_bwd<<<grid_for(m, n), kThreads, 0, s>>>(r, norm, g_norm, power, g_ax, m);
+    return check_launch();
+}
+
+// ===================================================================== unfused tail of step_bwd
+__global__ __launch_bounds__(kThreads) void k_clamp_scale(const float *__restrict__ g_x0,
+                                                          const float *__restrict__ norm,
+                                                          const uint8_t *__restrict__ ins, float scale, int power,
+                                                          float *__restrict__ g_mo, int64_t chw, Coefs k)
+{
+    const int64_t p = blockIdx.y, i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= chw) return;
+    const float coef = norm_coef(norm[p], scale, power);  // g_x0 holds A^T r; cotangent is coef * A^T r
+    const float gp = ins[p * chw + i] ? coef * g_x0[p * chw + i] : 0.0f;
+    g_mo[p * 2 * chw + i] = -k.b * gp;
+}
+
+int clamp_scale_to_eps(const float *g_x0, const float *norm, const uint8_t *inside, float scale, int power,
+                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
+{
+    if (n == 0 || chw == 0) return DPSX_OK;
+    k_clamp_scale<<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, norm, inside, scale, power, g_model_out, chw, k);
+    return check_launch();
+}
+
+// ===================================================================== S4 update
+// x_{t-1} = sample - (a*g_pre + g_unet),  a*g_pre = (-a/b) * g_eps
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_step_update(const float *__restrict__ sm,
+                                                          const float *__restrict__ g_mo,
+                                                          const float *__restrict__ gu, float *__restrict__ out,
+                                                          int64_t chw, float ratio)
+{
+    const int64_t p = blockIdx.y;
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= chw) return;
+    const int64_t o = p * chw + i, e = p * 2 * chw + i;
+    if constexpr (VEC) {
+        const float4 s4 = *reinterpret_cast<const float4 *>(sm + o);
+        const float4 g4 = *reinterpret_cast<const float4 *>(g_mo + e);
+        float4 u4 = make_float4(0, 0, 0, 0);
+        if (gu) u4 = *reinterpret_cast<const float4 *>(gu + o);
+        float4 r4;
+        r4.x = s4.x - (ratio * g4.x + u4.x);
+        r4.y = s4.y - (ratio * g4.y + u4.y);
+        r4.z = s4.z - (ratio * g4.z + u4.z);
+        r4.w = s4.w - (ratio * g4.w + u4.w);
+        *reinterpret_cast<float4 *>(out + o) = r4;
+    } else {
+        out[o] = sm[o] - (ratio * g_mo[e] + (gu ? gu[o] : 0.0f));
+    }
+}
+
+int step_update(const float *sample, const float *g_mo, const float *g_unet, float *x_next, int64_t n,
+                int64_t chw, const Coefs &k, hipStream_t s)
+{
+    if (n == 0 || chw == 0) return DPSX_OK;
+    const float ratio = -k.a / k.b;
+    const bool vec = chw % 4 == 0 && aligned16(sample) && aligned16(g_mo) && aligned16(g_unet) && aligned16(x_next);
+    if (vec)
+        k_step_update<true><<<grid_for(chw / 4, n), kThreads, 0, s>>>(sample, g_mo, g_unet, x_next, chw, ratio);
+    else
+        k_step_update<false><<<grid_for(chw, n), kThreads, 0, s>>>(sample, g_mo, g_unet, x_next, chw, ratio);
+    return check_launch();
+}
+
+__global__ __launch_bounds__(kThreads) void k_plain_update(const float *__restrict__ sm,
+                                                           const float *__restrict__ ga,
+                                                           const float *__restrict__ gb, float *__restrict__ out,
+                                                           int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count) return;
+    const float g = gb ? __fadd_rn(ga[i], gb[i]) : ga[i];
+    out[i] = __fsub_rn(sm[i], g);
+}
+
+int plain_update(const float *sample, const float *ga, const float *gb, float *out, int64_t count, hipStream_t s)
+{
+    if (count == 0) return DPSX_OK;
+    k_plain_update<<<(unsigned)((count + kThreads - 1) / kThreads), kThreads, 0, s>>>(sample, ga, gb, out, count);
+    return check_launch();
+}
+
+// ===================================================================== inpainting fused step
+// fwd: S1 + r = y - mask*x0 (not stored) + norm partials.   bwd: recompute r from x0_hat.
+__global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const float *__restrict__ mask,
+                                                            int64_t chw, int64_t hw)
+{
+    __shared__ float scratch[kThreads / kWave];
+    const int64_t p = blockIdx.y;
+    float acc = 0.0f;
+    // each block covers 4*kThreads consecutive elements of one particle
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i < chw) {
+        const int64_t o = p * chw + i, e = p * 2 * chw + i;
+        const float4 xv = *reinterpret_cast<const float4 *>(a.x_t + o);
+        const float4 ev = *reinterpret_cast<const float4 *>(a.model_out + e);
+        float4 vv = make_float4(0, 0, 0, 0), zv = vv;
+        if (a.k.add_noise) {
+            vv = *reinterpret_cast<const float4 *>(a.model_out + e + chw);
+            zv = *reinterpret_cast<const float4 *>(a.noise + o);
+        }
+        const float4 mv = *reinterpret_cast<const float4 *>(mask + (i % hw));
+        const float4 yv = *reinterpret_cast<const float4 *>(a.y + (a.y_n == 1 ? 0 : p) * chw + i);
+        bool b0, b1, b2, b3;
+        float4 x0, sm;
+        x0.x = post_x0(xv.x, ev.x, a.k, b0);
+        x0.y = post_x0(xv.y, ev.y, a.k, b1);
+        x0.z = post_x0(xv.z, ev.z, a.k, b2);
+        x0.w = post_x0(xv.w, ev.w, a.k, b3);
+        sm.x = post_sample(xv.x, x0.x, vv.x, zv.x, a.k);
+        sm.y = post_sample(xv.y, x0.y, vv.y, zv.y, a.k);
+        sm.z = post_sample(xv.z, x0.z, vv.z, zv.z, a.k);
+        sm.w = post_sample(xv.w, x0.w, vv.w, zv.w, a.k);
+        *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+        *reinterpret_cast<float4 *>(a.sample + o) = sm;
+        *reinterpret_cast<uchar4 *>(a.inside + o) = make_uchar4(b0, b1, b2, b3);
+        const float d0 = __fsub_rn(yv.x, __fmul_rn(x0.x, mv.x)), d1 = __fsub_rn(yv.y, __fmul_rn(x0.y, mv.y));
+        const float d2 = __fsub_rn(yv.z, __fmul_rn(x0.z, mv.z)), d3 = __fsub_rn(yv.w, __fmul_rn(x0.w, mv.w));
+        acc = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    const float t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) a.partials[p * gridDim.x + blockIdx.x] = t;
+}
+
+int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &a, int parts, hipStream_t s)
+{
+    const int64_t chw = a.c * a.h * a.w;
+    k_mask_step_fwd<<<dim3(parts, (unsigned)a.n), kThreads, 0, s>>>(a, op->mask, chw, a.h * a.w);
+    return check_launch();
+}
+
+__global__ __launch_bounds__(kThreads) void k_mask_step_bwd(StepBwdArgs a, const float *__restrict__ mask,
+                                                            int64_t chw, int64_t hw)
+{
+    const int64_t p = blockIdx.y;
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (i >= chw) return;
+    const int64_t o = p * chw + i;
+    const float coef = norm_coef(a.norm[p], a.scale, a.power);  // cotangent on A x0 is coef * r
+    const float4 x0 = *reinterpret_cast<const float4 *>(a.x0_hat + o);
+    const float4 mv = *reinterpret_cast<const float4 *>(mask + (i % hw));
+    const float4 yv = *reinterpret_cast<const float4 *>(a.y + (a.y_n == 1 ? 0 : p) * chw + i);
+    const uchar4 in = *reinterpret_cast<const uchar4 *>(a.inside + o);
+    float4 g;
+    // A^T = multiply by mask again; then clamp gate; then d/d eps = -b
+    g.x = in.x ? -a.k.b * (coef * __fsub_rn(yv.x, __fmul_rn(x0.x, mv.x)) * mv.x) : 0.0f;
+    g.y = in.y ? -a.k.b * (coef * __fsub_rn(yv.y, __fmul_rn(x0.y, mv.y)) * mv.y) : 0.0f;
+    g.z = in.z ? -a.k.b * (coef * __fsub_rn(yv.z, __fmul_rn(x0.z, mv.z)) * mv.z) : 0.0f;
+    g.w = in.w ? -a.k.b * (coef * __fsub_rn(yv.w, __fmul_rn(x0.w, mv.w)) * mv.w) : 0.0f;
+    *reinterpret_cast<float4 *>(a.g_model_out + p * 2 * chw + i) = g;
+}
+
+int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s)
+{
+    const int64_t chw = a.c * a.h * a.w;
+    k_mask_step_bwd<<<grid_for(chw / 4, a.n), kThreads, 0, s>>>(a, op->mask, chw, a.h * a.w);
+    return check_launch();
+}
+
+// ===================================================================== select
+// torch.argmin: first minimum; NaN is the minimum.  One block; n is small (<= a few thousand).
+__global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v, int64_t n, int64_t *__restrict__ out)
+{
+    __shared__ float s_val[kThreads];
+    __shared__ int64_t s_idx[kThreads];
+    float best = 0.0f;
+    int64_t bi = -1;
+    bool best_nan = false;
+    for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+        const float x = v[i];
+        const bool xn = x != x;
+        if (bi < 0 || (!best_nan && (xn || x < best))) { best = x; bi = i; best_nan = xn; }
+    }
+    s_val[threadIdx.x] = best;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = 0.0f;
+        int64_t ix = -1;
+        bool bn = false;
+        for (int t = 0; t < kThreads; ++t) {
+            const int64_t j = s_idx[t];
+            if (j < 0) continue;
+            const float x = s_val[t];
+            const bool xn = x != x;
+            bool take;
+            if (ix < 0) take = true;
+            else if (bn) take = xn && j < ix;
+            else if (xn) take = true;
+            else take = x < b || (x == b && j < ix);
+            if (take) { b = x; ix = j; bn = xn; }
+        }
+        *out = ix < 0 ? 0 : ix;
+    }
+}
+
+int argmin_f32(const float *v, int64_t n, int64_t *idx, hipStream_t s)
+{
+    k_argmin<<<1, kThreads, 0, s>>>(v, n, idx);
+    return check_launch();
+}
+
+__global__ __launch_bounds__(kThreads) void k_gather(const float *__restrict__ src, const int64_t *__restrict__ ids,
+                                                     float *__restrict__ dst, int64_t n_src, int64_t chw4,
+                                                     int replicate)
+{
+    const int64_t p = blockIdx.y;
+    int64_t sidx = replicate ? ids[0] : ids[p];
+    if (sidx < 0 || sidx >= n_src) return;  // never read out of bounds; caller validates ids
+    const float4 *s4 = reinterpret_cast<const float4 *>(src) + sidx * chw4;
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + p * chw4;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < chw4) d4[i] = s4[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_gather_scalar(const float *__restrict__ src,
+                                                            const int64_t *__restrict__ ids,
+                                                            float *__restrict__ dst, int64_t n_src, int64_t chw,
+                                                            int replicate)
+{
+    const int64_t p = blockIdx.y;
+    int64_t sidx = replicate ? ids[0] : ids[p];
+    if (sidx < 0 || sidx >= n_src) return;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < chw) dst[p * chw + i] = src[sidx * chw + i];
+}
+
+int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
+               bool replicate, hipStream_t s)
+{
+    if (n_out == 0 || chw == 0) return DPSX_OK;
+    if (chw % 4 == 0 && aligned16(src) && aligned16(dst))
+        k_gather<<<grid_for(chw / 4, n_out), kThreads, 0, s>>>(src, ids, dst, n_src, chw / 4, replicate);
+    else
+        k_gather_scalar<<<grid_for(chw, n_out), kThreads, 0, s>>>(src, ids, dst, n_src, chw, replicate);
+    return check_launch();
+}
+
+}  // namespace dpsx

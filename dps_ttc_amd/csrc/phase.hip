@@ -1,0 +1,238 @@
+// Phase-retrieval operator  A(x) = | F_c( zero-pad(x) ) |  with F_c the centred
+// orthonormal 2-D FFT (reference: measurements.py:179-189, util/img_utils.py:26-30,
+// util/fastmri_utils.py:67-89: ifftshift -> fftn(norm="ortho") -> fftshift).
+//
+// The FFT itself is the library transform (hipFFT/rocFFT, batched C2C, in place);
+// everything around it is hand-written and fused into two element-wise passes:
+//   pre  : zero-pad + ifftshift folded into the load index, real -> complex;
+//   post : fftshift folded into the index, 1/s scaling, modulus, and -- in the
+//          fused step -- residual y-|z|, per-block sums of squares, and the
+//          cotangent w = (y-|z|) z/|z| written over the spectrum in place;
+//   crop : after the (unnormalised) inverse FFT, undo shift + padding, real part.
+// s = h + 2*pad is even, so both shifts are a roll by s/2.
+#include <hipfft/hipfft.h>
+
+#include <map>
+
+#include "common.h"
+
+namespace dpsx {
+
+constexpr int PT = 256;
+constexpr int kChunk = 4096;  // spectrum elements per block in the reducing pass
+
+struct PhaseHost {
+    std::map<int64_t, hipfftHandle> plans;  // batch -> plan
+};
+
+static PhaseHost *host_of(const dpsx_op *op) { return static_cast<PhaseHost *>(op->fft_plan); }
+
+static int get_plan(dpsx_op *op, int64_t planes, hipfftHandle *out)
+{
+    PhaseHost *h = host_of(op);
+    auto it = h->plans.find(planes);
+    if (it != h->plans.end()) { *out = it->second; return DPSX_OK; }
+    const int s = (int)(op->pr_h + 2 * op->pr_pad);
+    int dims[2] = {s, s};
+    hipfftHandle plan;
+    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, s * s, nullptr, 1, s * s, HIPFFT_C2C, (int)planes) !=
+        HIPFFT_SUCCESS)
+        return DPSX_ENOMEM;
+    h->plans[planes] = plan;
+    *out = plan;
+    return DPSX_OK;
+}
+
+int phase_create(dpsx_op *op)
+{
+    op->fft_plan = new PhaseHost();
+    op->has_plan = true;
+    hipfftHandle p;
+    int rc = get_plan(op, op->pr_planes, &p);  // build the plan for the expected batch up front
+    if (rc != DPSX_OK) phase_destroy(op);
+    return rc;
+}
+
+void phase_destroy(dpsx_op *op)
+{
+    PhaseHost *h = host_of(op);
+    if (!h) return;
+    for (auto &kv : h->plans) (void)hipfftDestroy(kv.second);
+    delete h;
+    op->fft_plan = nullptr;
+}
+
+int64_t phase_workspace_bytes(const dpsx_op *op, int64_t planes)
+{
+    const int64_t s = op->pr_h + 2 * op->pr_pad;
+    return (planes * s * s * 8 + 255) / 256 * 256;
+}
+
+int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c)
+{
+    const int64_t s = op->pr_h + 2 * op->pr_pad;
+    return c * ((s * s + kChunk - 1) / kChunk);
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ __launch_bounds__(PT) void k_phase_pre(const float *__restrict__ x, float2 *__restrict__ q, int h,
+                                                  int pad, int s)
+{
+    const int64_t plane = blockIdx.y;
+    const int idx = blockIdx.x * PT + threadIdx.x;
+    if (idx >= s * s) return;
+    const int u = idx / s, v = idx - u * s, half = s / 2;
+    int i = u + half, j = v + half;  // ifftshift: Q[u][v] = P[(u - s/2) mod s][(v - s/2) mod s]
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    float val = 0.0f;
+    if (i >= pad && i < pad + h && j >= pad && j < pad + h) val = x[plane * h * h + (int64_t)(i - pad) * h + (j - pad)];
+    q[plane * s * s + idx] = make_float2(val, 0.0f);
+}
+
+// MODE 0: amp (+ optional centred spectrum) out.
+// MODE 1: fused step: r = y - |z|, sums of squares, z <- r z/|z| in place.
+// MODE 2: adjoint at a point: z <- u z/|z| in place (u given in centred layout).
+template <int MODE>
+__global__ __launch_bounds__(PT) void k_phase_post(float2 *__restrict__ z, float *__restrict__ amp,
+                                                   float2 *__restrict__ spec, const float *__restrict__ yu,
+                                                   int y_n, int c, float *__restrict__ partials, int s)
+{
+    __shared__ float scratch[PT / kWave];
+    const int64_t plane = blockIdx.y;
+    const int64_t ss = (int64_t)s * s;
+    const int half = s / 2;
+    const float inv = 1.0f / (float)s;
+    float acc = 0.0f;
+    const int base = blockIdx.x * kChunk;
+    for (int t = threadIdx.x; t < kChunk; t += PT) {
+        const int idx = base + t;
+        if (idx >= ss) break;
+        const int k = idx / s, q = idx - k * s;
+        int ok = k + half, oq = q + half;  // fftshift: centred[(k + s/2) mod s] = Z[k]
+        ok = ok >= s ? ok - s : ok;
+        oq = oq >= s ? oq - s : oq;
+        const int64_t cidx = (int64_t)ok * s + oq;
+        float2 zz = z[plane * ss + idx];
+        zz.x *= inv;
+        zz.y *= inv;
+        const float mag = sqrtf(zz.x * zz.x + zz.y * zz.y);
+        if (MODE == 0) {
+            amp[plane * ss + cidx] = mag;
+            if (spec) spec[plane * ss + cidx] = zz;
+        } else {
+            const int n = (int)(plane / c), ch = (int)(plane % c);
+            const int64_t yo = ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * ss + cidx;
+            float g;
+            if (MODE == 1) {
+                g = yu[yo] - mag;
+                acc = fmaf(g, g, acc);
+            } else {
+                g = yu[plane * ss + cidx];
+            }
+            const float f = mag == 0.0f ? 0.0f : g / mag;  // torch: d|z| = 0 at z = 0
+            z[plane * ss + idx] = make_float2(f * zz.x, f * zz.y);
+        }
+    }
+    if (MODE == 1) {
+        const float t = block_sum(acc, scratch);
+        const int chunks = gridDim.x;
+        const int n = (int)(plane / c), ch = (int)(plane % c);
+        if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * chunks + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(PT) void k_phase_crop(const float2 *__restrict__ v, float *__restrict__ g, int h,
+                                                   int pad, int s)
+{
+    const int64_t plane = blockIdx.y;
+    const int idx = blockIdx.x * PT + threadIdx.x;
+    if (idx >= h * h) return;
+    const int a = idx / h, b = idx - a * h, half = s / 2;
+    int i = a + pad + half, j = b + pad + half;  // undo ifftshift: P[i][j] = Q[(i + s/2) mod s][...]
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    g[plane * h * h + idx] = v[plane * s * s + (int64_t)i * s + j].x * (1.0f / (float)s);
+}
+
+// ---------------------------------------------------------------- host
+static int run_fft(dpsx_op *op, float2 *buf, int64_t planes, int dir, hipStream_t s)
+{
+    hipfftHandle plan;
+    int rc = get_plan(op, planes, &plan);
+    if (rc != DPSX_OK) return rc;
+    if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(buf), reinterpret_cast<hipfftComplex *>(buf), dir) !=
+        HIPFFT_SUCCESS)
+        return DPSX_ELAUNCH;
+    return DPSX_OK;
+}
+
+static int spectrum_of(dpsx_op *op, const float *x, float2 *buf, int64_t planes, hipStream_t s)
+{
+    const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
+    k_phase_pre<<<dim3((sz * sz + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(x, buf, h, pad, sz);
+    int rc = check_launch();
+    if (rc != DPSX_OK) return rc;
+    return run_fft(op, buf, planes, HIPFFT_FORWARD, s);
+}
+
+int phase_forward(dpsx_op *op, const float *x, float *amp, float *spec, int64_t planes, void *ws,
+                  int64_t ws_bytes, hipStream_t s)
+{
+    if (planes == 0) return DPSX_OK;
+    if (!ws || ws_bytes < phase_workspace_bytes(op, planes)) return DPSX_EWORKSPACE;
+    const int sz = (int)(op->pr_h + 2 * op->pr_pad);
+    float2 *buf = static_cast<float2 *>(ws);
+    int rc = spectrum_of(op, x, buf, planes, s);
+    if (rc != DPSX_OK) return rc;
+    const unsigned chunks = (unsigned)((sz * sz + kChunk - 1) / kChunk);
+    k_phase_post<0><<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(buf, amp, reinterpret_cast<float2 *>(spec),
+                                                                   nullptr, 1, 1, nullptr, sz);
+    return check_launch();
+}
+
+int phase_adjoint(dpsx_op *op, const float *u, const float *x, float *g, int64_t planes, void *ws,
+                  int64_t ws_bytes, hipStream_t s)
+{
+    if (planes == 0) return DPSX_OK;
+    if (!ws || ws_bytes < phase_workspace_bytes(op, planes)) return DPSX_EWORKSPACE;
+    const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
+    float2 *buf = static_cast<float2 *>(ws);
+    int rc = spectrum_of(op, x, buf, planes, s);
+    if (rc != DPSX_OK) return rc;
+    const unsigned chunks = (unsigned)((sz * sz + kChunk - 1) / kChunk);
+    k_phase_post<2><<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(buf, nullptr, nullptr, u, 0, 1, nullptr, sz);
+    if ((rc = check_launch()) != DPSX_OK) return rc;
+    if ((rc = run_fft(op, buf, planes, HIPFFT_BACKWARD, s)) != DPSX_OK) return rc;
+    k_phase_crop<<<dim3((h * h + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(buf, g, h, pad, sz);
+    return check_launch();
+}
+
+int phase_step_fwd(dpsx_op *op, const float *x0_hat, const float *y, int64_t y_n, float *resid_c,
+                   float *partials, int64_t n, int64_t c, hipStream_t s)
+{
+    const int64_t planes = n * c;
+    if (planes == 0) return DPSX_OK;
+    const int sz = (int)(op->pr_h + 2 * op->pr_pad);
+    float2 *buf = reinterpret_cast<float2 *>(resid_c);
+    int rc = spectrum_of(op, x0_hat, buf, planes, s);
+    if (rc != DPSX_OK) return rc;
+    const unsigned chunks = (unsigned)((sz * sz + kChunk - 1) / kChunk);
+    k_phase_post<1><<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(buf, nullptr, nullptr, y, (int)y_n, (int)c,
+                                                                   partials, sz);
+    return check_launch();
+}
+
+int phase_step_bwd(dpsx_op *op, float *resid_c, float *g_x0, int64_t planes, hipStream_t s)
+{
+    if (planes == 0) return DPSX_OK;
+    const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
+    float2 *buf = reinterpret_cast<float2 *>(resid_c);
+    int rc = run_fft(op, buf, planes, HIPFFT_BACKWARD, s);
+    if (rc != DPSX_OK) return rc;
+    k_phase_crop<<<dim3((h * h + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(buf, g_x0, h, pad, sz);
+    return check_launch();
+}
+
+}  // namespace dpsx

@@ -1,0 +1,492 @@
+// Super-resolution operator: Shocher's Resizer as used by SuperResolutionOperator
+// (reference: util/resizer.py:55-74, measurements.py:76-91).  Per axis
+//     out[o] = sum_k wt[k, o] * x[idx[k, o]]
+// W axis first, then H (Resizer.sorted_dims == [3, 2] for equal scales).  The
+// tables are arbitrary (reflection is baked into idx), so the kernels are
+// table-driven gathers staged through LDS:
+//   forward : one workgroup per (plane, block of output rows): the input rows
+//             that block needs (plus the rows it "owns" in the fused step) are
+//             streamed HBM -> LDS once with 16-byte loads, W pass LDS -> LDS,
+//             H pass LDS -> registers, residual / sum-of-squares epilogue;
+//   adjoint : gather form over a CSR inverse of the tables (input index ->
+//             list of (output index, weight)), so no atomics and a
+//             deterministic summation order; one workgroup per (plane, block
+//             of input rows); u (the small measurement-space tensor) is read
+//             once into LDS, g is written with coalesced rows.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace dpsx {
+
+constexpr int RT = 256;  // threads
+
+struct ResizeDev {
+    const float *w_h, *w_w;   // [taps, out]
+    const int *i_h, *i_w;     // [taps, out]
+    const int *inv_h_ptr, *inv_h_idx, *inv_w_ptr, *inv_w_idx;
+    const float *inv_h_w, *inv_w_w;
+    int in_h, in_w, out_h, out_w, taps_h, taps_w;
+    // forward blocking
+    int tp;                   // output rows per block
+    int fwd_rows;             // max input rows staged per block
+    const int *blk_lo;        // [nblk] first staged input row
+    const int *blk_cnt;       // [nblk] number of staged rows
+    const int *own_lo;        // [nblk+1] input-row ownership partition (fused step)
+    // adjoint blocking
+    int ti;                   // input rows per block
+    int adj_rows;             // max u rows staged per block
+    const int *ablk_lo, *ablk_cnt;
+};
+
+struct ResizeArgs {
+    const float *x;           // plain input [planes, in_h, in_w] / adjoint input u [planes, out_h, out_w]
+    float *out;               // fwd: A x or residual (nullable when RESID); adj: g
+    const float *x_t, *model_out, *noise;
+    float *x0_hat, *sample;
+    uint8_t *inside_w;
+    const float *y;
+    int y_n;
+    float *partials;
+    const float *norm_in;
+    const uint8_t *inside_r;
+    float *g_model_out;
+    float scale;
+    int power;
+    int c, planes;
+    Coefs k;
+};
+
+__device__ __forceinline__ float norm_coef_r(float nv, float gn, int power)
+{
+    return power == 2 ? -2.0f * gn : (nv == 0.0f ? 0.0f : -gn / nv);
+}
+
+// LDS: s_in[fwd_rows][in_w] | s_tmp[fwd_rows][out_w] | s_red[8]
+template <bool POST, bool RESID, bool VEC>
+__global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds, *s_tmp = lds + d.fwd_rows * d.in_w, *s_red = s_tmp + d.fwd_rows * d.out_w;
+    const int nblk = (d.out_h + d.tp - 1) / d.tp;
+    const int plane = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int lo = d.blk_lo[blk], cnt = d.blk_cnt[blk];
+    const int64_t ihw = (int64_t)d.in_h * d.in_w, ohw = (int64_t)d.out_h * d.out_w;
+    const int n = plane / a.c, ch = plane % a.c;
+    // ---- stage A: rows [lo, lo+cnt) -> LDS
+    {
+        const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+        int olo = 0, ohi = 0;
+        if constexpr (POST) {
+            src = a.x_t + (int64_t)plane * ihw;
+            eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * ihw;
+            vv = eps + (int64_t)a.c * ihw;
+            zz = a.noise + (int64_t)plane * ihw;
+            olo = d.own_lo[blk];
+            ohi = d.own_lo[blk + 1];
+        } else {
+            src = a.x + (int64_t)plane * ihw;
+        }
+        constexpr int U = VEC ? 4 : 1;
+        const int wu = d.in_w / U;
+        for (int u = threadIdx.x; u < cnt * wu; u += RT) {
+            const int rr = u / wu, cu = u - rr * wu;
+            const int gy = lo + rr, gx = cu * U;
+            const int64_t o = (int64_t)gy * d.in_w + gx;
+            float val[U];
+            if constexpr (VEC) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + o);
+                val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
+            } else {
+                val[0] = src[o];
+            }
+            if constexpr (POST) {
+                float ev[U], xin[U];
+                bool ins[U];
+                if constexpr (VEC) {
+                    const float4 q = *reinterpret_cast<const float4 *>(eps + o);
+                    ev[0] = q.x; ev[1] = q.y; ev[2] = q.z; ev[3] = q.w;
+                } else {
+                    ev[0] = eps[o];
+                }
+#pragma unroll
+                for (int e = 0; e < U; ++e) {
+                    xin[e] = val[e];
+                    val[e] = post_x0(xin[e], ev[e], a.k, ins[e]);
+                }
+                if (gy >= olo && gy < ohi) {
+                    float vq[U], zq[U], sm[U];
+                    if constexpr (VEC) {
+                        float4 t4 = make_float4(0, 0, 0, 0), z4 = t4;
+                        if (a.k.add_noise) {
+                            t4 = *reinterpret_cast<const float4 *>(vv + o);
+                            z4 = *reinterpret_cast<const float4 *>(zz + o);
+                        }
+                        vq[0] = t4.x; vq[1] = t4.y; vq[2] = t4.z; vq[3] = t4.w;
+                        zq[0] = z4.x; zq[1] = z4.y; zq[2] = z4.z; zq[3] = z4.w;
+                    } else {
+                        vq[0] = a.k.add_noise ? vv[o] : 0.0f;
+                        zq[0] = a.k.add_noise ? zz[o] : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < U; ++e) sm[e] = post_sample(xin[e], val[e], vq[e], zq[e], a.k);
+                    const int64_t po = (int64_t)plane * ihw + o;
+                    if constexpr (VEC) {
+                        *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                        *reinterpret_cast<float4 *>(a.sample + po) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+                        *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
+                    } else {
+                        a.x0_hat[po] = val[0];
+                        a.sample[po] = sm[0];
+                        a.inside_w[po] = ins[0];
+                    }
+                }
+            }
+            float *dst = s_in + rr * d.in_w + gx;
+            if constexpr (VEC) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+            else dst[0] = val[0];
+        }
+    }
+    __syncthreads();
+    // ---- stage B: W pass  tmp[r][o] = sum_k w_w[k,o] * in[r][i_w[k,o]]
+    for (int it = threadIdx.x; it < cnt * d.out_w; it += RT) {
+        const int rr = it / d.out_w, o = it - rr * d.out_w;
+        const float *row = s_in + rr * d.in_w;
+        float acc = 0.0f;
+        for (int k = 0; k < d.taps_w; ++k)
+            acc = fmaf(d.w_w[k * d.out_w + o], row[d.i_w[k * d.out_w + o]], acc);
+        s_tmp[rr * d.out_w + o] = acc;
+    }
+    __syncthreads();
+    // ---- stage C: H pass  out[p][o] = sum_k w_h[k,p] * tmp[i_h[k,p] - lo][o]
+    float ss = 0.0f;
+    const int p0 = blk * d.tp, p1 = min(d.out_h, p0 + d.tp);
+    for (int it = threadIdx.x; it < (p1 - p0) * d.out_w; it += RT) {
+        const int p = p0 + it / d.out_w, o = it % d.out_w;
+        float acc = 0.0f;
+        for (int k = 0; k < d.taps_h; ++k)
+            acc = fmaf(d.w_h[k * d.out_h + p], s_tmp[(d.i_h[k * d.out_h + p] - lo) * d.out_w + o], acc);
+        const int64_t oo = (int64_t)p * d.out_w + o;
+        if constexpr (RESID) {
+            const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
+            const float r = yv - acc;
+            if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
+            ss = fmaf(r, r, ss);
+        } else {
+            a.out[(int64_t)plane * ohw + oo] = acc;
+        }
+    }
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+    }
+}
+
+// LDS: s_u[adj_rows][out_w] | s_t[ti][out_w]
+template <bool EPI, bool VEC>
+__global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *s_u = lds, *s_t = lds + d.adj_rows * d.out_w;
+    const int nblk = (d.in_h + d.ti - 1) / d.ti;
+    const int plane = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int lo = d.ablk_lo[blk], cnt = d.ablk_cnt[blk];
+    const int64_t ihw = (int64_t)d.in_h * d.in_w, ohw = (int64_t)d.out_h * d.out_w;
+    const float *up = a.x + (int64_t)plane * ohw + (int64_t)lo * d.out_w;
+    for (int u = threadIdx.x; u < cnt * d.out_w; u += RT) s_u[u] = up[u];
+    __syncthreads();
+    const int i0 = blk * d.ti, i1 = min(d.in_h, i0 + d.ti);
+    // H adjoint: T[i][o] = sum_{e in inv_h[i]} w_e * u[p_e][o]
+    for (int it = threadIdx.x; it < (i1 - i0) * d.out_w; it += RT) {
+        const int ii = it / d.out_w, o = it - ii * d.out_w;
+        const int e0 = d.inv_h_ptr[i0 + ii], e1 = d.inv_h_ptr[i0 + ii + 1];
+        float acc = 0.0f;
+        for (int e = e0; e < e1; ++e) acc = fmaf(d.inv_h_w[e], s_u[(d.inv_h_idx[e] - lo) * d.out_w + o], acc);
+        s_t[ii * d.out_w + o] = acc;
+    }
+    __syncthreads();
+    float coef = 0.0f;
+    const int n = plane / a.c, ch = plane % a.c;
+    if constexpr (EPI) coef = norm_coef_r(a.norm_in[n], a.scale, a.power);
+    // W adjoint: g[i][j] = sum_{e in inv_w[j]} w_e * T[i][o_e]
+    constexpr int U = VEC ? 4 : 1;
+    const int wu = d.in_w / U;
+    for (int it = threadIdx.x; it < (i1 - i0) * wu; it += RT) {
+        const int ii = it / wu, j0 = (it - ii * wu) * U;
+        float g[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int e0 = d.inv_w_ptr[j0 + q], e1 = d.inv_w_ptr[j0 + q + 1];
+            float acc = 0.0f;
+            for (int e = e0; e < e1; ++e) acc = fmaf(d.inv_w_w[e], s_t[ii * d.out_w + d.inv_w_idx[e]], acc);
+            g[q] = acc;
+        }
+        const int64_t o = (int64_t)(i0 + ii) * d.in_w + j0;
+        if constexpr (EPI) {
+            const uint8_t *ip = a.inside_r + (int64_t)plane * ihw + o;
+            float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * ihw + o;
+            const float mb = -a.k.b;
+            if constexpr (VEC) {
+                const uchar4 in = *reinterpret_cast<const uchar4 *>(ip);
+                float4 r;
+                r.x = in.x ? mb * (coef * g[0]) : 0.0f;
+                r.y = in.y ? mb * (coef * g[1]) : 0.0f;
+                r.z = in.z ? mb * (coef * g[2]) : 0.0f;
+                r.w = in.w ? mb * (coef * g[3]) : 0.0f;
+                *reinterpret_cast<float4 *>(gp) = r;
+            } else {
+                gp[0] = ip[0] ? mb * (coef * g[0]) : 0.0f;
+            }
+        } else {
+            float *gp = a.out + (int64_t)plane * ihw + o;
+            if constexpr (VEC) *reinterpret_cast<float4 *>(gp) = make_float4(g[0], g[1], g[2], g[3]);
+            else gp[0] = g[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host
+struct ResizeHost {
+    ResizeDev dev{};
+    std::vector<void *> allocs;
+};
+
+template <typename T>
+static int upload(ResizeHost *h, const std::vector<T> &v, const T **out)
+{
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    DPSX_HIP_TRY(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (!v.empty()) DPSX_HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(p);
+    return DPSX_OK;
+}
+
+static void build_inverse(const float *w, const int64_t *idx, int64_t taps, int64_t n_out, int64_t n_in,
+                          std::vector<int> &ptr, std::vector<int> &oidx, std::vector<float> &ow)
+{
+    // CSR by input index; entries ordered by (output index, tap) -> deterministic summation order
+    std::vector<std::vector<std::pair<int, float>>> rows((size_t)n_in);
+    for (int64_t o = 0; o < n_out; ++o)
+        for (int64_t k = 0; k < taps; ++k) {
+            const float wt = w[k * n_out + o];
+            if (wt == 0.0f) continue;
+            rows[(size_t)idx[k * n_out + o]].push_back({(int)o, wt});
+        }
+    ptr.assign((size_t)n_in + 1, 0);
+    for (int64_t i = 0; i < n_in; ++i) ptr[(size_t)i + 1] = ptr[(size_t)i] + (int)rows[(size_t)i].size();
+    oidx.clear();
+    ow.clear();
+    for (auto &r : rows)
+        for (auto &e : r) {
+            oidx.push_back(e.first);
+            ow.push_back(e.second);
+        }
+}
+
+constexpr size_t kLdsBudget = 96 * 1024;
+
+int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float *w_w, const int64_t *i_w)
+{
+    auto *h = new ResizeHost();
+    ResizeDev &d = h->dev;
+    d.in_h = (int)op->in_h; d.in_w = (int)op->in_w; d.out_h = (int)op->out_h; d.out_w = (int)op->out_w;
+    d.taps_h = (int)op->taps_h; d.taps_w = (int)op->taps_w;
+    for (int64_t i = 0; i < op->taps_h * op->out_h; ++i)
+        if (i_h[i] < 0 || i_h[i] >= op->in_h) { delete h; return DPSX_EINVAL; }
+    for (int64_t i = 0; i < op->taps_w * op->out_w; ++i)
+        if (i_w[i] < 0 || i_w[i] >= op->in_w) { delete h; return DPSX_EINVAL; }
+    std::vector<float> vwh(w_h, w_h + op->taps_h * op->out_h), vww(w_w, w_w + op->taps_w * op->out_w);
+    std::vector<int> vih((size_t)(op->taps_h * op->out_h)), viw((size_t)(op->taps_w * op->out_w));
+    for (size_t i = 0; i < vih.size(); ++i) vih[i] = (int)i_h[i];
+    for (size_t i = 0; i < viw.size(); ++i) viw[i] = (int)i_w[i];
+    int rc;
+#define UP(vec, field) if ((rc = upload(h, vec, &d.field)) != DPSX_OK) { for (void *p : h->allocs) (void)hipFree(p); delete h; return rc; }
+    UP(vwh, w_h) UP(vww, w_w) UP(vih, i_h) UP(viw, i_w)
+    std::vector<int> ptr, oi;
+    std::vector<float> ow;
+    build_inverse(w_h, i_h, op->taps_h, op->out_h, op->in_h, ptr, oi, ow);
+    std::vector<int> hp = ptr, hi = oi;
+    std::vector<float> hw = ow;
+    UP(hp, inv_h_ptr) UP(hi, inv_h_idx) UP(hw, inv_h_w)
+    build_inverse(w_w, i_w, op->taps_w, op->out_w, op->in_w, ptr, oi, ow);
+    UP(ptr, inv_w_ptr) UP(oi, inv_w_idx) UP(ow, inv_w_w)
+
+    // ---- forward blocking: largest tp (<= 16) whose staged rows fit the LDS budget
+    int best_tp = 0;
+    std::vector<int> blo, bcnt, own;
+    for (int tp = 16; tp >= 1; tp >>= 1) {
+        const int nblk = (d.out_h + tp - 1) / tp;
+        std::vector<int> lo((size_t)nblk), cnt((size_t)nblk), ow_((size_t)nblk + 1);
+        int maxrows = 0;
+        for (int b = 0; b <= nblk; ++b) ow_[(size_t)b] = (int)((int64_t)b * d.in_h / nblk);
+        for (int b = 0; b < nblk; ++b) {
+            int mn = ow_[(size_t)b], mx = ow_[(size_t)b + 1] - 1;  // staged range covers the owned rows too
+            for (int p = b * tp; p < std::min(d.out_h, (b + 1) * tp); ++p)
+                for (int k = 0; k < d.taps_h; ++k) {
+                    const int v = vih[(size_t)k * d.out_h + p];
+                    mn = std::min(mn, v);
+                    mx = std::max(mx, v);
+                }
+            lo[(size_t)b] = mn;
+            cnt[(size_t)b] = mx - mn + 1;
+            maxrows = std::max(maxrows, mx - mn + 1);
+        }
+        const size_t lds = ((size_t)maxrows * (d.in_w + d.out_w) + 16) * 4;
+        if (lds <= kLdsBudget || tp == 1) {
+            best_tp = tp; d.fwd_rows = maxrows; blo = lo; bcnt = cnt; own = ow_;
+            if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
+            break;
+        }
+    }
+    d.tp = best_tp;
+    UP(blo, blk_lo) UP(bcnt, blk_cnt) UP(own, own_lo)
+    // ---- adjoint blocking
+    int best_ti = 0;
+    std::vector<int> alo, acnt;
+    for (int ti = 32; ti >= 1; ti >>= 1) {
+        const int nblk = (d.in_h + ti - 1) / ti;
+        std::vector<int> lo((size_t)nblk), cnt((size_t)nblk);
+        int maxrows = 1;
+        for (int b = 0; b < nblk; ++b) {
+            int mn = d.out_h, mx = -1;
+            for (int i = b * ti; i < std::min(d.in_h, (b + 1) * ti); ++i)
+                for (int e = hp[(size_t)i]; e < hp[(size_t)i + 1]; ++e) {
+                    mn = std::min(mn, hi[(size_t)e]);
+                    mx = std::max(mx, hi[(size_t)e]);
+                }
+            if (mx < mn) { mn = 0; mx = 0; }
+            lo[(size_t)b] = mn;
+            cnt[(size_t)b] = mx - mn + 1;
+            maxrows = std::max(maxrows, mx - mn + 1);
+        }
+        const size_t lds = ((size_t)(maxrows + ti) * d.out_w) * 4;
+        if (lds <= kLdsBudget || ti == 1) {
+            best_ti = ti; d.adj_rows = maxrows; alo = lo; acnt = cnt;
+            if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
+            break;
+        }
+    }
+    d.ti = best_ti;
+    UP(alo, ablk_lo) UP(acnt, ablk_cnt)
+#undef UP
+    op->d_w_h = reinterpret_cast<float *>(h);  // opaque owner pointer (see resize_destroy)
+    return DPSX_OK;
+}
+
+void resize_destroy(dpsx_op *op)
+{
+    auto *h = reinterpret_cast<ResizeHost *>(op->d_w_h);
+    if (!h) return;
+    for (void *p : h->allocs) (void)hipFree(p);
+    delete h;
+    op->d_w_h = nullptr;
+}
+
+static const ResizeDev &dev_of(const dpsx_op *op) { return reinterpret_cast<const ResizeHost *>(op->d_w_h)->dev; }
+
+int64_t resize_parts_per_particle(const dpsx_op *op, int64_t c)
+{
+    const ResizeDev &d = dev_of(op);
+    return c * ((d.out_h + d.tp - 1) / d.tp);
+}
+
+template <typename K>
+static int allow_lds(K kernel, bool &done)
+{
+    if (!done) {
+        DPSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        done = true;
+    }
+    return DPSX_OK;
+}
+
+#define RZ_LAUNCH(KERNEL, GRID, LDS, STREAM, ...)                                   \
+    do {                                                                             \
+        static bool s_done = false;                                                  \
+        int rc_ = allow_lds(&KERNEL, s_done);                                        \
+        if (rc_ != DPSX_OK) return rc_;                                              \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(RT), LDS, STREAM, __VA_ARGS__);  \
+        return check_launch();                                                       \
+    } while (0)
+
+template <bool POST, bool RESID>
+static int launch_fwd(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStream_t s)
+{
+    const ResizeDev &d = dev_of(op);
+    const unsigned grid = (unsigned)(a.planes * ((d.out_h + d.tp - 1) / d.tp));
+    const size_t lds = ((size_t)d.fwd_rows * (d.in_w + d.out_w) + 16) * 4;
+    if (vec) RZ_LAUNCH((k_resize_fwd<POST, RESID, true>), grid, lds, s, a, d);
+    RZ_LAUNCH((k_resize_fwd<POST, RESID, false>), grid, lds, s, a, d);
+}
+
+template <bool EPI>
+static int launch_adj(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStream_t s)
+{
+    const ResizeDev &d = dev_of(op);
+    const unsigned grid = (unsigned)(a.planes * ((d.in_h + d.ti - 1) / d.ti));
+    const size_t lds = ((size_t)(d.adj_rows + d.ti) * d.out_w) * 4;
+    if (vec) RZ_LAUNCH((k_resize_adj<EPI, true>), grid, lds, s, a, d);
+    RZ_LAUNCH((k_resize_adj<EPI, false>), grid, lds, s, a, d);
+}
+
+static bool rz_vec(const dpsx_op *op, std::initializer_list<const void *> ptrs)
+{
+    if (op->in_w % 4 != 0) return false;
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+int resize_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, hipStream_t s)
+{
+    if (planes == 0) return DPSX_OK;
+    ResizeArgs a{};
+    a.x = x; a.out = y; a.c = 1; a.planes = (int)planes;
+    return launch_fwd<false, false>(op, a, rz_vec(op, {x}), s);
+}
+
+int resize_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, hipStream_t s)
+{
+    if (planes == 0) return DPSX_OK;
+    ResizeArgs a{};
+    a.x = u; a.out = g; a.c = 1; a.planes = (int)planes;
+    return launch_adj<false>(op, a, rz_vec(op, {g}), s);
+}
+
+int resize_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
+{
+    if (f.n == 0) return DPSX_OK;
+    ResizeArgs a{};
+    a.x_t = f.x_t; a.model_out = f.model_out; a.noise = f.noise; a.x0_hat = f.x0_hat; a.sample = f.sample;
+    a.inside_w = f.inside; a.y = f.y; a.y_n = (int)f.y_n; a.out = f.resid; a.partials = f.partials;
+    a.c = (int)f.c; a.planes = (int)(f.n * f.c); a.k = f.k;
+    const bool vec = rz_vec(op, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample}) &&
+                     (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
+    return launch_fwd<true, true>(op, a, vec, s);
+}
+
+int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
+{
+    if (b.n == 0) return DPSX_OK;
+    ResizeArgs a{};
+    a.x = b.resid; a.norm_in = b.norm; a.inside_r = b.inside; a.g_model_out = b.g_model_out;
+    a.scale = b.scale; a.power = b.power; a.c = (int)b.c; a.planes = (int)(b.n * b.c); a.k = b.k;
+    const bool vec = rz_vec(op, {b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
+    return launch_adj<true>(op, a, vec, s);
+}
+
+int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,
+                 int64_t c, hipStream_t s)
+{
+    if (n == 0) return DPSX_OK;
+    ResizeArgs a{};
+    a.x = x; a.y = y; a.y_n = (int)y_n; a.out = nullptr; a.partials = partials; a.c = (int)c;
+    a.planes = (int)(n * c);
+    return launch_fwd<false, true>(op, a, rz_vec(op, {x}), s);
+}
+
+}  // namespace dpsx

@@ -1,0 +1,340 @@
+"""torch-tensor front end of the C ABI (include/dpsx.h) + the autograd glue.
+
+Every function here enqueues hand-written HIP kernels on torch's current
+stream; tensors are only the owners of device memory.  Nothing in this module
+computes with torch ops.
+"""
+import ctypes
+from ctypes import byref, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Coefs, check, f32c, lib, ptr, require_cuda, stream_of
+
+
+def make_coefs(a, b, c1, c2, min_log, max_log, add_noise):
+    return Coefs(float(a), float(b), float(c1), float(c2), float(min_log), float(max_log), int(bool(add_noise)))
+
+
+# ------------------------------------------------------------------ S1
+def posterior_fwd(x_t, model_out, noise, coefs, want_inside=False):
+    """p_mean_variance + DDPM.p_sample (gaussian_diffusion.py:308-330, 466-476) -> (x0_hat, sample[, inside])."""
+    x_t, model_out = f32c(x_t, "x_t"), f32c(model_out, "model_out")
+    noise = None if noise is None else f32c(noise, "noise")
+    n, chw = x_t.shape[0], x_t[0].numel() if x_t.shape[0] else 0
+    if model_out.shape[0] != n or (n and model_out[0].numel() != 2 * chw):
+        raise ValueError(f"model_out {tuple(model_out.shape)} does not hold 2x the channels of x {tuple(x_t.shape)}")
+    x0, sample = torch.empty_like(x_t), torch.empty_like(x_t)
+    inside = torch.empty(x_t.shape, dtype=torch.uint8, device=x_t.device) if want_inside else None
+    check(lib().dpsx_posterior_fwd_f32(ptr(x_t), ptr(model_out), ptr(noise), ptr(x0), ptr(sample), ptr(inside),
+                                       n, chw, byref(coefs), stream_of(x_t)), "dpsx_posterior_fwd_f32")
+    return (x0, sample, inside) if want_inside else (x0, sample)
+
+
+def posterior_bwd(g_x0, g_sample, x_t, model_out, noise, coefs):
+    x_t, model_out = f32c(x_t), f32c(model_out)
+    g_x0 = None if g_x0 is None else f32c(g_x0)
+    g_sample = None if g_sample is None else f32c(g_sample)
+    noise = None if noise is None else f32c(noise)
+    n, chw = x_t.shape[0], x_t[0].numel() if x_t.shape[0] else 0
+    g_x, g_mo = torch.empty_like(x_t), torch.empty_like(model_out)
+    check(lib().dpsx_posterior_bwd_f32(ptr(g_x0), ptr(g_sample), ptr(x_t), ptr(model_out), ptr(noise), ptr(g_x),
+                                       ptr(g_mo), n, chw, byref(coefs), stream_of(x_t)), "dpsx_posterior_bwd_f32")
+    return g_x, g_mo
+
+
+class PosteriorStepFn(torch.autograd.Function):
+    """(x_t, model_out) -> (x0_hat, sample) with the HIP VJP, so torch.autograd only sees UNet -> [HIP tail]."""
+
+    @staticmethod
+    def forward(ctx, x_t, model_out, noise, coefs):
+        x0, sample = posterior_fwd(x_t, model_out, noise, coefs)
+        ctx.save_for_backward(x_t, model_out, noise if noise is not None else x_t.new_empty(0))
+        ctx.coefs = coefs
+        return x0, sample
+
+    @staticmethod
+    def backward(ctx, g_x0, g_sample):
+        x_t, model_out, noise = ctx.saved_tensors
+        g_x, g_mo = posterior_bwd(g_x0, g_sample, x_t, model_out, noise if noise.numel() else None, ctx.coefs)
+        return g_x, g_mo, None, None
+
+
+# ------------------------------------------------------------------ operator handles
+class OpHandle:
+    """Owns one dpsx_op (constant tables on the device) and its scratch workspace."""
+
+    def __init__(self, handle, device, keep=()):
+        self._h = handle
+        self.device = device
+        self._keep = keep          # tensors the op borrows (mask)
+        self._ws = None
+        self.kind = lib().dpsx_op_kind(self._h)
+
+    @classmethod
+    def blur(cls, kernel2d, device, force_taps=False):
+        k = np.ascontiguousarray(np.asarray(kernel2d, dtype=np.float32))
+        if k.ndim != 2 or k.shape[0] != k.shape[1]:
+            raise ValueError("blur kernel must be square")
+        _cuda_device(device)
+        h = c_void_p()
+        check(lib().dpsx_op_create_blur(k.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), k.shape[0],
+                                        _lib.BLUR_FORCE_TAPS if force_taps else _lib.BLUR_AUTO, byref(h)),
+              "dpsx_op_create_blur")
+        return cls(h, device)
+
+    @classmethod
+    def resize(cls, in_h, in_w, w_h, i_h, w_w, i_w, device):
+        w_h = np.ascontiguousarray(w_h, dtype=np.float32)
+        w_w = np.ascontiguousarray(w_w, dtype=np.float32)
+        i_h = np.ascontiguousarray(i_h, dtype=np.int64)
+        i_w = np.ascontiguousarray(i_w, dtype=np.int64)
+        _cuda_device(device)
+        h = c_void_p()
+        fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+        check(lib().dpsx_op_create_resize(in_h, in_w, w_h.ctypes.data_as(fp), i_h.ctypes.data_as(ip),
+                                          w_h.shape[0], w_h.shape[1], w_w.ctypes.data_as(fp),
+                                          i_w.ctypes.data_as(ip), w_w.shape[0], w_w.shape[1], byref(h)),
+              "dpsx_op_create_resize")
+        return cls(h, device)
+
+    @classmethod
+    def mask(cls, mask, device):
+        m = f32c(mask.to(device), "mask")
+        hh, ww = m.shape[-2:]
+        if m.numel() != hh * ww:
+            raise ValueError("mask must be [1,1,H,W]")
+        h = c_void_p()
+        check(lib().dpsx_op_create_mask(ptr(m), hh, ww, byref(h)), "dpsx_op_create_mask")
+        return cls(h, device, keep=(m,))
+
+    @classmethod
+    def identity(cls, device):
+        _cuda_device(device)
+        h = c_void_p()
+        check(lib().dpsx_op_create_identity(byref(h)), "dpsx_op_create_identity")
+        return cls(h, device)
+
+    @classmethod
+    def phase(cls, side, pad, max_planes, device):
+        _cuda_device(device)
+        h = c_void_p()
+        check(lib().dpsx_op_create_phase(side, pad, max_planes, byref(h)), "dpsx_op_create_phase")
+        return cls(h, device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib._lib is not None:
+            _lib._lib.dpsx_op_destroy(h)
+
+    # -- geometry / scratch
+    def out_hw(self, h, w):
+        oh, ow = c_int64(), c_int64()
+        check(lib().dpsx_op_out_shape(self._h, h, w, byref(oh), byref(ow)), "dpsx_op_out_shape")
+        return oh.value, ow.value
+
+    def workspace(self, n, c, h, w, device):
+        need = lib().dpsx_op_workspace_bytes(self._h, n, c, h, w)
+        if need < 0:
+            check(int(need), "dpsx_op_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
+        return self._ws
+
+    # -- A and A^T
+    def forward(self, x):
+        x = _nchw(f32c(x, "operator input"))
+        n, c, h, w = x.shape
+        oh, ow = self.out_hw(h, w)
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+        ws = self.workspace(n, c, h, w, x.device)
+        check(lib().dpsx_op_forward_f32(self._h, ptr(x), ptr(y), n, c, h, w, ptr(ws), ws.numel(), stream_of(x)),
+              "dpsx_op_forward_f32")
+        return y
+
+    def adjoint(self, u, x=None, in_hw=None):
+        u = _nchw(f32c(u, "cotangent"))
+        n, c = u.shape[:2]
+        h, w = in_hw if in_hw is not None else x.shape[-2:]
+        x = None if x is None else f32c(x)
+        g = torch.empty((n, c, h, w), dtype=torch.float32, device=u.device)
+        ws = self.workspace(n, c, h, w, u.device)
+        check(lib().dpsx_op_adjoint_f32(self._h, ptr(u), ptr(x), ptr(g), n, c, h, w, ptr(ws), ws.numel(),
+                                        stream_of(u)), "dpsx_op_adjoint_f32")
+        return g
+
+    def score(self, x, y):
+        """costs[p] = ||y - A(x_p)||_2 (gaussian_diffusion.py:626-630) without materialising A x."""
+        x, y = _nchw(f32c(x)), f32c(y)
+        n, c, h, w = x.shape
+        costs = torch.empty(n, dtype=torch.float32, device=x.device)
+        ws = self.workspace(n, c, h, w, x.device)
+        check(lib().dpsx_score_f32(self._h, ptr(x), ptr(y), y.shape[0], ptr(costs), n, c, h, w, ptr(ws),
+                                   ws.numel(), stream_of(x)), "dpsx_score_f32")
+        return costs
+
+
+def _cuda_device(device):
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"dps_ttc_amd operators need an MI355X device, got {dev} (no CPU fallback by design)")
+    torch.cuda.set_device(dev)
+    torch.cuda.current_stream(dev)   # make sure the HIP context exists before libdpsx allocates
+
+
+def _nchw(t):
+    if t.dim() != 4:
+        raise ValueError(f"expected an [N,C,H,W] tensor, got {tuple(t.shape)}")
+    return t
+
+
+class OperatorFn(torch.autograd.Function):
+    """operator.forward with its exact HIP adjoint as the VJP."""
+
+    @staticmethod
+    def forward(ctx, x, handle):
+        ctx.handle = handle
+        ctx.in_hw = tuple(x.shape[-2:])
+        if handle.kind == _lib.KIND_PHASE:
+            ctx.save_for_backward(x)
+        return handle.forward(x)
+
+    @staticmethod
+    def backward(ctx, u):
+        x = ctx.saved_tensors[0] if ctx.handle.kind == _lib.KIND_PHASE else None
+        return ctx.handle.adjoint(u, x=x, in_hw=ctx.in_hw), None
+
+
+# ------------------------------------------------------------------ residual norm
+def residual_norm(y, ax, want_residual=True):
+    y, ax = f32c(y, "measurement"), f32c(ax, "A x")
+    n = ax.shape[0]
+    m = ax[0].numel() if n else 0
+    y_n = y.shape[0]
+    if y_n not in (1, n) or (n and y[0].numel() != m):
+        raise ValueError(f"measurement {tuple(y.shape)} does not broadcast against {tuple(ax.shape)}")
+    r = torch.empty_like(ax) if want_residual else None
+    norm = torch.empty(n, dtype=torch.float32, device=ax.device)
+    ws = torch.empty(max(n * 256, 1), dtype=torch.float32, device=ax.device)
+    check(lib().dpsx_residual_norm_f32(ptr(y), y_n, ptr(ax), ptr(r), ptr(norm), n, m, ptr(ws), ws.numel() * 4,
+                                       stream_of(ax)), "dpsx_residual_norm_f32")
+    return r, norm
+
+
+def norm_bwd(r, norm, g_norm, power=1):
+    r, norm, g_norm = f32c(r), f32c(norm), f32c(g_norm)
+    n = r.shape[0]
+    g = torch.empty_like(r)
+    check(lib().dpsx_norm_bwd_f32(ptr(r), ptr(norm), ptr(g_norm), power, ptr(g), n, r[0].numel() if n else 0,
+                                  stream_of(r)), "dpsx_norm_bwd_f32")
+    return g
+
+
+class ResidualNormFn(torch.autograd.Function):
+    """norm[p] = ||y - ax_p||_2 per particle  (condition_methods.py:37-39); VJP w.r.t. ax only."""
+
+    @staticmethod
+    def forward(ctx, ax, y):
+        r, norm = residual_norm(y, ax)
+        ctx.save_for_backward(r, norm)
+        return norm
+
+    @staticmethod
+    def backward(ctx, g_norm):
+        r, norm = ctx.saved_tensors
+        return norm_bwd(r, norm, g_norm, 1), None
+
+
+# ------------------------------------------------------------------ update / select
+def update(sample, g_a, g_b=None):
+    sample, g_a = f32c(sample), f32c(g_a)
+    g_b = None if g_b is None else f32c(g_b)
+    out = torch.empty_like(sample)
+    check(lib().dpsx_update_f32(ptr(sample), ptr(g_a), ptr(g_b), ptr(out), sample.numel(), stream_of(sample)),
+          "dpsx_update_f32")
+    return out
+
+
+def argmin(v):
+    """torch.argmin semantics on the device, result stays on the device (int64 scalar tensor)."""
+    v = f32c(v.reshape(-1), "scores")
+    if v.numel() == 0:
+        raise ValueError("argmin of an empty score vector")
+    out = torch.empty((), dtype=torch.int64, device=v.device)
+    check(lib().dpsx_argmin_f32(ptr(v), v.numel(), ptr(out), stream_of(v)), "dpsx_argmin_f32")
+    return out
+
+
+def gather(src, ids):
+    """src[ids] for an [N, ...] fp32 tensor and int64 ids (gaussian_diffusion.py:697)."""
+    src = f32c(src)
+    ids = ids.to(device=src.device, dtype=torch.int64).contiguous()
+    if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= src.shape[0]):
+        raise IndexError("gather index out of range")
+    dst = torch.empty((ids.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    chw = src[0].numel() if src.shape[0] else 0
+    check(lib().dpsx_gather_f32(ptr(src), ptr(ids), ptr(dst), ids.numel(), src.shape[0], chw, stream_of(src)),
+          "dpsx_gather_f32")
+    return dst
+
+
+def replicate(src, idx_dev, n_out=None):
+    """img[best.repeat(n)] (gaussian_diffusion.py:633): idx stays on the device, no host sync."""
+    src = f32c(src)
+    n_out = src.shape[0] if n_out is None else n_out
+    idx_dev = idx_dev.to(device=src.device, dtype=torch.int64).reshape(1).contiguous()
+    dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    chw = src[0].numel() if src.shape[0] else 0
+    check(lib().dpsx_replicate_f32(ptr(src), ptr(idx_dev), ptr(dst), n_out, src.shape[0], chw, stream_of(src)),
+          "dpsx_replicate_f32")
+    return dst
+
+
+# ------------------------------------------------------------------ fused DPS step
+class StepBuffers:
+    """Persistent per-(N, C, H, W) device buffers of the fused step (resident in HBM across steps)."""
+
+    def __init__(self, handle, n, c, h, w, device):
+        self.shape = (n, c, h, w)
+        f = dict(dtype=torch.float32, device=device)
+        self.x0_hat = torch.empty((n, c, h, w), **f)
+        self.sample = torch.empty((n, c, h, w), **f)
+        self.inside = torch.empty((n, c, h, w), dtype=torch.uint8, device=device)
+        self.norm = torch.empty(n, **f)
+        rb = lib().dpsx_step_resid_bytes(handle._h, n, c, h, w)
+        if rb < 0:
+            check(int(rb), "dpsx_step_resid_bytes")
+        self.resid = torch.empty(max(int(rb), 256), dtype=torch.uint8, device=device)
+        # variance half of the UNet-output cotangent is identically zero for the DPS loss: zeroed once
+        self.g_model_out = torch.zeros((n, 2 * c, h, w), **f)
+        self.x_next = [torch.empty((n, c, h, w), **f), torch.empty((n, c, h, w), **f)]
+        self.flip = 0
+
+
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs):
+    n, c, h, w = buf.shape
+    ws = handle.workspace(n, c, h, w, x_t.device)
+    check(lib().dpsx_step_fwd_f32(handle._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0],
+                                  ptr(buf.x0_hat), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid), ptr(buf.norm),
+                                  n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(x_t)),
+          "dpsx_step_fwd_f32")
+
+
+def step_bwd(handle, buf, y, scale, power, coefs):
+    n, c, h, w = buf.shape
+    ws = handle.workspace(n, c, h, w, buf.x0_hat.device)
+    check(lib().dpsx_step_bwd_f32(handle._h, ptr(buf.resid), ptr(buf.norm), ptr(buf.inside), ptr(buf.x0_hat),
+                                  ptr(y), y.shape[0], float(scale), int(power), ptr(buf.g_model_out),
+                                  n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(buf.x0_hat)),
+          "dpsx_step_bwd_f32")
+
+
+def step_update(buf, g_unet, coefs):
+    n, c, h, w = buf.shape
+    out = buf.x_next[buf.flip]
+    buf.flip ^= 1
+    check(lib().dpsx_step_update_f32(ptr(buf.sample), ptr(buf.g_model_out), ptr(g_unet), ptr(out), n, c * h * w,
+                                     byref(coefs), stream_of(buf.sample)), "dpsx_step_update_f32")
+    return out

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particles x denoise-steps / s of the DPS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): FFHQ-shaped 256x256 RGB,
+Gaussian deblur sigma=3.0 (61x61 kernel), N=64 particles per GPU, 'ps' conditioning (scale 0.3).
+One step = the whole non-UNet DPS step over the particle batch -- S1 posterior arithmetic, A(x0_hat) + residual
++ norm, the cotangent back through A^T / clamp to the UNet output, and the update -- three fused HIP launches
+(+ a one-block norm finalisation).  The UNet is not in the timed region: its output (model_out) and its VJP
+(g_unet) are synthetic device-resident tensors, cycled through a small ring so no step re-reads
+warm lines; x_t chains from step to step as in the real loop, t cycles 999 -> 0 with the real fp32 tables.
+
+Multi-GPU: particles shard across ranks (64 per GPU, weak scaling), no collective inside the step; the timed
+region ends with the global best-of-N select (RCCL all-gather of the per-particle scores + winner broadcast).
+
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the fused S1+blur+residual launch) from
+live event timing, `cpu_baseline` is the oracle (a CPU port of the reference path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P_BYTES = 3 * 256 * 256 * 4                    # one fp32 particle image
+ALGO_BYTES = {"fwd": 8 * P_BYTES,              # S1 6P + S2 (1+rho)P, rho = 1      
+              "bwd": 5 * P_BYTES,              # S3 (4+rho)P
+              "upd": 4 * P_BYTES}              # S4 4P          -> 17P per particle-step
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
+    ap.add_argument("--operator", default="gaussian_blur", choices=["gaussian_blur", "motion_blur",
+                                                                    "super_resolution", "inpainting"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def synth_inputs(n, ring, device, seed):
+    """torch.manual_seed(1234) on the CPU, then copied to HBM."""
+    g = torch.Generator().manual_seed(seed)
+    shape = (n, 3, 256, 256)
+    x_t = torch.randn(shape, generator=g)
+    sets = []
+    for _ in range(ring):
+        eps = torch.randn(shape, generator=g)
+        v = torch.rand(shape, generator=g) * 2 - 1
+        sets.append({"model_out": torch.cat([eps, v], dim=1).to(device),
+                     "noise": torch.randn(shape, generator=g).to(device),
+                     "g_unet": (torch.randn(shape, generator=g) * 1e-2).to(device)})
+    truth = torch.rand((1, 3, 256, 256), generator=g) * 2 - 1
+    meas_noise = torch.randn((1, 3, 256, 256), generator=g) * 0.05
+    return x_t.to(device), sets, truth, meas_noise
+
+
+def build_operator(name, device):
+    from dps_ttc_amd.measurements import get_operator
+    if name == "gaussian_blur":
+        return get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device=device), {}
+    if name == "motion_blur":
+        np.random.seed(0)
+        return get_operator("motion_blur", kernel_size=61, intensity=0.5, device=device), {}
+    if name == "super_resolution":
+        return get_operator("super_resolution", in_shape=(1, 3, 256, 256), scale_factor=4, device=device), {}
+    g = torch.Generator().manual_seed(7)
+    mask = (torch.rand((1, 1, 256, 256), generator=g) < 0.5).float().to(device)
+    return get_operator("inpainting", device=device), {"mask": mask}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from dps_ttc_amd import distributed as dd
+    from dps_ttc_amd import kernels
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    from dps_ttc_amd.measurements import get_noise
+
+    n = args.particles
+    op, fkw = build_operator(args.operator, device)
+    cm = get_conditioning_method("ps", op, get_noise("gaussian", sigma=0.05), scale=0.3)
+    smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="")
+    x_t, ring, truth, meas_noise = synth_inputs(n, 3, device, 1234 + rank)
+    y = (op.forward(truth.to(device), **fkw).detach() + meas_noise.to(device)
+         if args.operator != "super_resolution" else None)
+    if y is None:
+        yy = op.forward(truth.to(device)).detach()
+        y = yy + meas_noise.to(device)[..., :yy.shape[-2], :yy.shape[-1]]
+    y = y.contiguous()
+    handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
+    buf = kernels.StepBuffers(handle, n, 3, 256, 256, device)
+    spec = cm.fused_spec()
+
+    def step(i, x, timers=None):
+        t = 999 - (i % 1000)
+        ck = smp.step_coefs[t]
+        s = ring[i % len(ring)]
+        if timers is not None:
+            timers[0].record()
+        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck)
+        if timers is not None:
+            timers[1].record()
+        kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], ck)
+        if timers is not None:
+            timers[2].record()
+        out = kernels.step_update(buf, s["g_unet"], ck)
+        if timers is not None:
+            timers[3].record()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    x = x_t
+    for i in range(args.warmup):
+        x = step(i, x)
+    if world > 1:     # warm the collectives too
+        dd.global_best_of_n(buf.norm.clone(), x)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = step(args.warmup + i, x)
+    winner, best, _ = dd.global_best_of_n(buf.norm, x)      # final best-of-N over all ranks' particles
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
+    reps = min(args.steps, 50)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for i in range(reps):
+        x = step(args.warmup + args.steps + i, x, evs[i])
+    torch.cuda.synchronize()
+    dur = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) * 1e-3
+           for j, k in enumerate(("fwd", "bwd", "upd"))}
+
+    if rank == 0:
+        total = n * world
+        value = total * args.steps / elapsed
+        dom = max(dur, key=dur.get)
+        kernel_names = {"fwd": "S1 + A(x0_hat) + residual + norm partials (k_blur_sep_fwd<3,POST,RESID>)",
+                        "bwd": "A^T + clamp gate + -b*coef (k_blur_sep_adj<3,EPI>)",
+                        "upd": "x_{t-1} = sample - (a g_pre + g_unet) (k_step_update)"}
+        achieved = ALGO_BYTES[dom] * n / dur[dom] / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.operator, {}).get(dom)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "particles×denoise-steps/sec @256×256 N=64; x0_hat rel-L2 vs ref",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FFHQ-shaped 256x256 {args.operator} (sigma=3.0, k=61), 'ps' scale 0.3, "
+                                   f"best-of-N N={n}/GPU, DDPM t cycling 999->0",
+                       "particles_per_gpu": n, "global_particles": total, "image": "3x256x256",
+                       "parallelism": f"particles sharded x{world}, score all-gather at the select"},
+            "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n,
+                         "avg_launch_ms": dur[dom] * 1e3,
+                         "all_launches_ms": {k: v * 1e3 for k, v in dur.items()},
+                         "step_frac_of_hbm_roofline": (17 * P_BYTES * n / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS},
+            "best_of_n_index": best,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.operator == "gaussian_blur":
+            line["cpu_baseline"], line["x0_hat_rel_l2"] = cpu_baseline(args, smp, ring, x_t, y, handle, device)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, smp, ring, x_t, y, handle, device):
+    """The oracle (plain-C port of the reference step, OpenMP) on the host cores, same inputs, bounded sample.
+    Also yields the parity figure of the metric: rel-L2 of the HIP x0_hat / x_{t-1} against it."""
+    import oracle
+    from dps_ttc_amd import kernels
+    nc, steps = min(args.cpu_particles, x_t.shape[0]), args.cpu_steps
+    orc = oracle.make_operator("gaussian_blur", kernel_size=61, intensity=3.0)
+    sched = oracle.tables.schedule(1000)
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    x = x_t[:nc].cpu().numpy()
+    yh = y.cpu().numpy()
+    sets = [{k: v[:nc].cpu().numpy() for k, v in s.items()} for s in ring]
+    orc.forward(x[:1])                       # page in the library outside the timed region
+    t0 = time.perf_counter()
+    outs = []
+    for i in range(steps):
+        t = 999 - i
+        s = sets[i % len(sets)]
+        c = oracle.tables.step_coefs(sched, t)
+        r = oracle.dps_step(orc, x, s["model_out"], s["noise"], yh, c, scale=0.3, power=1,
+                            g_unet_fn=lambda g, gu=s["g_unet"]: gu)
+        outs.append(r)
+        x = r["x_next"]
+    dt = time.perf_counter() - t0
+    # parity of the same steps on the GPU
+    buf = kernels.StepBuffers(handle, nc, 3, 256, 256, device)
+    xg = x_t[:nc].contiguous()
+    worst = 0.0
+    for i in range(steps):
+        ck = smp.step_coefs[999 - i]
+        s = ring[i % len(ring)]
+        kernels.step_fwd(handle, buf, xg, s["model_out"][:nc].contiguous(), s["noise"][:nc].contiguous(), y, ck)
+        kernels.step_bwd(handle, buf, y, 0.3, 1, ck)
+        xg = kernels.step_update(buf, s["g_unet"][:nc].contiguous(), ck)
+        for a, b in ((buf.x0_hat, outs[i]["x0_hat"]), (xg, outs[i]["x_next"])):
+            a = a.cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())))
+    return ({"value": nc * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+             "sample": f"{nc} particles x {steps} steps of the same workload (oracle/dps_oracle.c, OpenMP, "
+                       f"zero taps of the 61x61 kernel skipped), {dt:.1f} s"}, worst)
+
+
+if __name__ == "__main__":
+    main()

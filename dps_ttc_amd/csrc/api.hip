@@ -42,7 +42,9 @@ int dpsx_posterior_fwd_f32(const float *x_t, const float *model_out, const float
                            float *sample, uint8_t *inside, int64_t n, int64_t chw,
                            const dpsx_coefs *coefs_host, void *stream)
 {
-    if (!x_t || !model_out || !coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
+    if (!coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
+    if (n == 0 || chw == 0) return DPSX_OK;   // empty particle set: nothing to do (pointers may be null)
+    if (!x_t || !model_out) return DPSX_EINVAL;
     if (coefs_host->add_noise && !noise) return DPSX_EINVAL;
     return posterior_fwd(x_t, model_out, noise, x0_hat, sample, inside, n, chw, to_coefs(coefs_host),
                          (hipStream_t)stream);
@@ -52,7 +54,9 @@ int dpsx_posterior_bwd_f32(const float *g_x0, const float *g_sample, const float
                            const float *noise, float *g_x, float *g_model_out, int64_t n, int64_t chw,
                            const dpsx_coefs *coefs_host, void *stream)
 {
-    if (!x_t || !model_out || !g_x || !g_model_out || !coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
+    if (!coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
+    if (n == 0 || chw == 0) return DPSX_OK;
+    if (!x_t || !model_out || !g_x || !g_model_out) return DPSX_EINVAL;
     if (coefs_host->add_noise && g_sample && !noise) return DPSX_EINVAL;
     return posterior_bwd(g_x0, g_sample, x_t, model_out, noise, g_x, g_model_out, n, chw, to_coefs(coefs_host),
                          (hipStream_t)stream);
@@ -539,14 +543,18 @@ int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, void *strea
 int dpsx_gather_f32(const float *src, const int64_t *ids_dev, float *dst, int64_t n_out, int64_t n_src,
                     int64_t chw, void *stream)
 {
-    if (!src || !ids_dev || !dst || n_out < 0 || n_src < 1 || chw < 0 || src == dst) return DPSX_EINVAL;
+    if (n_out < 0 || chw < 0) return DPSX_EINVAL;
+    if (n_out == 0 || chw == 0) return DPSX_OK;
+    if (!src || !ids_dev || !dst || n_src < 1 || src == dst) return DPSX_EINVAL;
     return gather_f32(src, ids_dev, dst, n_out, n_src, chw, false, (hipStream_t)stream);
 }
 
 int dpsx_replicate_f32(const float *src, const int64_t *idx_dev, float *dst, int64_t n_out, int64_t n_src,
                        int64_t chw, void *stream)
 {
-    if (!src || !idx_dev || !dst || n_out < 0 || n_src < 1 || chw < 0 || src == dst) return DPSX_EINVAL;
+    if (n_out < 0 || chw < 0) return DPSX_EINVAL;
+    if (n_out == 0 || chw == 0) return DPSX_OK;
+    if (!src || !idx_dev || !dst || n_src < 1 || src == dst) return DPSX_EINVAL;
     return gather_f32(src, idx_dev, dst, n_out, n_src, chw, true, (hipStream_t)stream);
 }
 

@@ -144,6 +144,8 @@ class GaussianDiffusion:
                            for t in range(self.num_timesteps)]
         #: draw noise on the host generator in the reference's order (parity tests); default: on the device
         self.rng_parity = False
+        #: strides of the reference run's measurement tensor (only read when rng_parity is set)
+        self.parity_measurement_stride = None
         self.progress = False
         self.last_measurement_distance = None
         self.last_semantic_distance = None
@@ -151,15 +153,19 @@ class GaussianDiffusion:
         self._bufs = None
 
     # -- RNG ---------------------------------------------------------------
-    def _randn(self, like):
+    def _randn(self, like, stride=None):
         if self.rng_parity:
-            return torch.randn(like.shape, dtype=torch.float32).to(like.device)
+            # replay of the reference's host RNG stream (tests): torch's CPU normal_() consumes the
+            # generator differently for non-contiguous tensors, so the layout is part of the stream
+            proxy = torch.empty(like.shape, dtype=torch.float32) if stride is None else \
+                torch.empty_strided(tuple(like.shape), tuple(stride), dtype=torch.float32)
+            return torch.randn_like(proxy).contiguous().to(like.device)
         return torch.randn_like(like, dtype=torch.float32)
 
     # -- q ------------------------------------------------------------------
     def q_sample(self, x_start, t):
         """reference :134-151 (two scalars times tensors: not worth a kernel, result unused by ps*)"""
-        noise = self._randn(x_start)
+        noise = self._randn(x_start, self.parity_measurement_stride)
         t = int(t)
         return float(np.float32(self.sqrt_alphas_cumprod[t])) * x_start + \
             float(np.float32(self.sqrt_one_minus_alphas_cumprod[t])) * noise
@@ -275,7 +281,8 @@ class GaussianDiffusion:
             if plan is not None:
                 noise = self._randn(img)
                 if self.rng_parity:
-                    self._randn(measurement)         # the reference's q_sample draw (:224), result unused by ps*
+                    # the reference's q_sample draw (:224), result unused by ps*
+                    self._randn(measurement, self.parity_measurement_stride)
                 img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise)
             else:
                 img = img.detach().requires_grad_()

@@ -253,6 +253,10 @@ def main():
                                              measurement=y, measurement_cond_fn=cond, record=False,
                                              save_root=None)
         out[f"{tag}.y"] = np32(y)
+        # the reference's q_sample draws randn_like(y) every step; Resizer returns a transposed view, and
+        # torch's CPU normal_() consumes the generator differently for non-contiguous tensors, so the
+        # RNG stream depends on y's strides: record them for the parity replay
+        out[f"{tag}.y_stride"] = np.asarray(y.stride(), dtype=np.int64)
         out[f"{tag}.x_start"] = np32(x_start)
         out[f"{tag}.rng_seed"] = np.int64(seed + 1)
         out[f"{tag}.final"] = np32(img)

@@ -369,6 +369,7 @@ def test_base_loop_golden(K, golden, tag, oname, resp, scale, norm_exp, fused):
             norms.append(host(r[1]).copy())
             return r
     model = StandInModel().to(DEV)
+    smp.parity_measurement_stride = tuple(int(v) for v in g[f"{tag}.y_stride"])
     torch.manual_seed(int(g[f"{tag}.rng_seed"]))
     img, dist, sem = smp.p_sample_loop(model=model, x_start=dev(g[f"{tag}.x_start"]).requires_grad_(),
                                        measurement=dev(g[f"{tag}.y"]), measurement_cond_fn=cond, record=False,
@@ -414,6 +415,7 @@ def test_ttc_driver_call_returns_bare_tensor(K, golden):
     op, _ = make_product_op("sr4", hw=64)
     cm = get_conditioning_method("ps", op, get_noise("gaussian", sigma=0.05), scale=1.0)
     smp = _sampler("ddpm", "20")
+    smp.parity_measurement_stride = tuple(int(v) for v in g["sr4.r20.y_stride"])
     torch.manual_seed(int(g["sr4.r20.rng_seed"]))
     out = smp.p_sample_loop(model=StandInModel().to(DEV), x_start=dev(g["sr4.r20.x_start"]).requires_grad_(),
                             measurement=dev(g["sr4.r20.y"]), measurement_cond_fn=cm.conditioning, record=False,

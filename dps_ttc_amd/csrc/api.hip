@@ -113,14 +113,15 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
                     break;
                 }
     }
-    if (separable) {
-        op->kind = OP_SEP;
+    op->kind = separable ? OP_SEP : OP_TAPS;
+    if (separable)
         for (int d = -reach; d <= reach; ++d) {
             op->sep.v[reach4 + d] = (float)col[(size_t)(R + d)];
             op->sep.h[reach4 + d] = (float)row[(size_t)(R + d)];
         }
-    } else {
-        op->kind = OP_TAPS;
+    // the list of non-zero taps always exists: it is the whole implementation for non-separable kernels
+    // and the fallback of separable ones for shapes the 16-byte loader cannot take (w % 4 != 0)
+    {
         std::vector<int> dy, dx;
         std::vector<float> w;
         for (int i = 0; i < ks; ++i)

@@ -16,6 +16,8 @@
 //            adjoint the clamp gate and the -b * coef scaling into g_model_out.
 // Blocks are numbered so that the tiles of one plane share blockIdx % 8, i.e.
 // one XCD and its L2 (halo re-reads then hit L2, not HBM).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dpsx {
@@ -47,6 +49,7 @@ struct BlurArgs {
     const int *tap_dy, *tap_dx;
     const float *tap_w;
     int nnz;
+    int dbg;   // diagnostic phase mask (env DPSX_DBG), 0 in production
 };
 
 __device__ __forceinline__ bool block_to_tile(const BlurArgs &a, int &plane, int &ty, int &tx)
@@ -237,184 +240,7 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
     }
 }
 
-// =====================================================================
-// Separable path.  RR = padded radius (multiple of 4, <= 32); taps centred at index RR.
-// LDS: s_in[RH][SW] | s_tmp[RH][TW] | 256 floats of scratch
-// =====================================================================
-template <int RR>
-__device__ __forceinline__ void hpass_main(const float *s_in, float *s_tmp, const int SW, const int RH,
-                                           const float (&taps)[2 * kMaxRadius + 1])
-{
-    // items: (row, group of 8 outputs); window = 8 + 2*RR floats read as float4
-    constexpr int NG = TW / 8, NF = (8 + 2 * RR) / 4;
-    for (int it = threadIdx.x; it < RH * NG; it += NT) {
-        const int rr = it / NG, g = it - rr * NG;
-        const float *row = s_in + rr * SW + g * 8;
-        float acc[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(row + 4 * j);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    const int d = 4 * j + e - o;  // tap index (0 .. 2RR)
-                    if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], v[e], acc[o]);
-                }
-            }
-        }
-        float *dst = s_tmp + rr * TW + g * 8;
-        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    }
-}
-
-template <int RR>
-__device__ __forceinline__ void vpass_main(const float *s_tmp, float (&acc)[4][4], const int rg, const int cg,
-                                           const float (&taps)[2 * kMaxRadius + 1])
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4 + 2 * RR; ++j) {
-        const float4 v4 = *reinterpret_cast<const float4 *>(s_tmp + (4 * rg + j) * TW + 4 * cg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = j - i;
-            if (d >= 0 && d <= 2 * RR) {
-                acc[i][0] = fmaf(taps[d], v4.x, acc[i][0]);
-                acc[i][1] = fmaf(taps[d], v4.y, acc[i][1]);
-                acc[i][2] = fmaf(taps[d], v4.z, acc[i][2]);
-                acc[i][3] = fmaf(taps[d], v4.w, acc[i][3]);
-            }
-        }
-    }
-}
-
-template <int R4, bool POST, bool RESID, bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
-{
-    constexpr int RR = 4 * R4, RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
-    extern __shared__ __align__(16) float lds[];
-    float *s_in = lds, *s_tmp = lds + RH * SW, *s_red = s_tmp + RH * TW;
-    int plane, ty, tx;
-    if (!block_to_tile(a, plane, ty, tx)) return;
-    const int h0 = ty * TH, w0 = tx * TW;
-    load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
-    __syncthreads();
-    hpass_main<RR>(s_in, s_tmp, SW, RH, taps.h);
-    __syncthreads();
-    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    float acc[4][4];
-    vpass_main<RR>(s_tmp, acc, rg, cg, taps.v);
-    const int ox = w0 + 4 * cg;
-    float ss = 0.0f;
-    if (ox < a.w) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oy = h0 + 4 * rg + i;
-            if constexpr (RESID) ss += resid_epilogue<VEC>(a, plane, oy, ox, acc[i]);
-            else out_epilogue<VEC>(a, plane, oy, ox, acc[i], 0.0f, false);
-        }
-    }
-    if constexpr (RESID) {
-        const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
-    }
-}
-
-// Padded positions other than i itself that ReflectionPad maps onto image index i
-// (axis length n, pad R < n): -i for 1 <= i <= R, and 2(n-1)-i for n-1-R <= i <= n-2.
-__device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
-{
-    int cnt = 0;
-    if (i >= 1 && i <= R) p[cnt++] = -i;
-    if (i <= n - 2 && i >= n - 1 - R) p[cnt++] = 2 * (n - 1) - i;
-    return cnt;
-}
-
-template <int R4, bool EPI, bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps /* already flipped */, int radius)
-{
-    constexpr int RR = 4 * R4, RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
-    extern __shared__ __align__(16) float lds[];
-    float *s_in = lds, *s_tmp = lds + RH * SW, *s_th = s_tmp + RH * TW, *s_tv = s_th + 80;
-    int plane, ty, tx;
-    if (!block_to_tile(a, plane, ty, tx)) return;
-    const int h0 = ty * TH, w0 = tx * TW;
-    float coef = 0.0f;
-    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
-    for (int i = threadIdx.x; i <= 2 * RR; i += NT) {
-        s_th[i] = taps.h[i];
-        s_tv[i] = taps.v[i];
-    }
-    load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
-    __syncthreads();
-    // T[rr][c] = sum_d hflip[d] * u_z[row][c + d - RR]
-    hpass_main<RR>(s_in, s_tmp, SW, RH, taps.h);
-    __syncthreads();
-    // horizontal fold: columns 1..R also receive G[-j]; columns w-1-R..w-2 receive G[2(w-1)-j]
-    const bool wborder = (w0 <= radius) || (w0 + TW >= a.w - 1 - radius);
-    if (wborder) {
-        for (int it = threadIdx.x; it < RH * 2 * radius; it += NT) {
-            const int rr = it / (2 * radius), q = it - rr * 2 * radius;
-            const bool left = q < radius;
-            const int j = left ? 1 + q : a.w - 2 - (q - radius);
-            if (j < w0 || j >= w0 + TW || j < 0 || j >= a.w) continue;
-            if (!left && j >= 1 && j <= radius) continue;  // already owned by the left list
-            int src[2];
-            const int cnt = fold_sources(j, a.w, radius, src);
-            float add = 0.0f;
-            for (int s = 0; s < cnt; ++s) {
-                // G[p] = sum_d hflip[d] * u_z[p + d - RR]; region column = p - w0 + d
-                const int base = src[s] - w0;
-                for (int d = RR - radius; d <= RR + radius; ++d) {
-                    const int col = base + d;
-                    if (col >= 0 && col < RW) add = fmaf(s_th[d], s_in[rr * SW + col], add);
-                }
-            }
-            s_tmp[rr * TW + (j - w0)] += add;  // one item per (row, column): no two threads share a word
-        }
-        __syncthreads();
-    }
-    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    float acc[4][4];
-    vpass_main<RR>(s_tmp, acc, rg, cg, taps.v);
-    const bool hborder = (h0 <= radius) || (h0 + TH >= a.h - 1 - radius);
-    if (hborder) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oy = h0 + 4 * rg + i;
-            if (oy >= a.h) continue;
-            int src[2];
-            const int cnt = fold_sources(oy, a.h, radius, src);
-            for (int s = 0; s < cnt; ++s) {
-                const int base = src[s] - h0;  // region row = base + d
-                for (int d = RR - radius; d <= RR + radius; ++d) {
-                    const int row = base + d;
-                    if (row >= 0 && row < RH) {
-                        const float4 v4 = *reinterpret_cast<const float4 *>(s_tmp + row * TW + 4 * cg);
-                        const float t = s_tv[d];
-                        acc[i][0] = fmaf(t, v4.x, acc[i][0]);
-                        acc[i][1] = fmaf(t, v4.y, acc[i][1]);
-                        acc[i][2] = fmaf(t, v4.z, acc[i][2]);
-                        acc[i][3] = fmaf(t, v4.w, acc[i][3]);
-                    }
-                }
-            }
-        }
-    }
-    const int ox = w0 + 4 * cg;
-    if (ox < a.w) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out_epilogue<VEC>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
-    }
-}
+#include "blur_sep.h"
 
 // =====================================================================
 // Generic path: list of non-zero taps (dy, dx in [-R, R], weight), read through
@@ -528,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int ra
 constexpr size_t kScratchBytes = 1024;
 static inline size_t sep_lds_bytes(int rr)
 {
-    return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4) + (TH + 2 * rr) * TW) * 4 + kScratchBytes;
+    return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes;
 }
 static inline size_t taps_lds_bytes(int rr) { return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4)) * 4 + kScratchBytes; }
 
@@ -537,6 +363,8 @@ static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int
     a.c = (int)c; a.h = (int)h; a.w = (int)w; a.planes = (int)planes;
     a.tiles_x = (int)((w + TW - 1) / TW);
     a.tiles_y = (int)((h + TH - 1) / TH);
+    static const int dbg = getenv("DPSX_DBG") ? atoi(getenv("DPSX_DBG")) : 0;
+    a.dbg = dbg;
 }
 
 static inline unsigned grid_blocks(const BlurArgs &a)
@@ -573,39 +401,37 @@ static int allow_lds(K kernel, size_t bytes, bool &done)
     } while (0)
 
 template <int R4, bool POST, bool RESID>
-static int launch_sep_fwd(const BlurArgs &a, const SepTaps &t, bool vec, hipStream_t s)
+static int launch_sep_fwd(const BlurArgs &a, const SepTaps &t, hipStream_t s)
 {
     const size_t lds = sep_lds_bytes(4 * R4);
-    if (vec) DPSX_LAUNCH((k_blur_sep_fwd<R4, POST, RESID, true>), grid_blocks(a), lds, s, a, t);
-    DPSX_LAUNCH((k_blur_sep_fwd<R4, POST, RESID, false>), grid_blocks(a), lds, s, a, t);
+    DPSX_LAUNCH((k_blur_sep_fwd<R4, POST, RESID>), grid_blocks(a), lds, s, a, t);
 }
 
 template <bool POST, bool RESID>
-static int dispatch_sep_fwd(const dpsx_op *op, const BlurArgs &a, bool vec, hipStream_t s)
+static int dispatch_sep_fwd(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 {
     switch (op->radius4 / 4) {
-    case 1: return launch_sep_fwd<1, POST, RESID>(a, op->sep, vec, s);
-    case 2: return launch_sep_fwd<2, POST, RESID>(a, op->sep, vec, s);
-    case 3: return launch_sep_fwd<3, POST, RESID>(a, op->sep, vec, s);
-    case 4: return launch_sep_fwd<4, POST, RESID>(a, op->sep, vec, s);
-    case 5: return launch_sep_fwd<5, POST, RESID>(a, op->sep, vec, s);
-    case 6: return launch_sep_fwd<6, POST, RESID>(a, op->sep, vec, s);
-    case 7: return launch_sep_fwd<7, POST, RESID>(a, op->sep, vec, s);
-    case 8: return launch_sep_fwd<8, POST, RESID>(a, op->sep, vec, s);
+    case 1: return launch_sep_fwd<1, POST, RESID>(a, op->sep, s);
+    case 2: return launch_sep_fwd<2, POST, RESID>(a, op->sep, s);
+    case 3: return launch_sep_fwd<3, POST, RESID>(a, op->sep, s);
+    case 4: return launch_sep_fwd<4, POST, RESID>(a, op->sep, s);
+    case 5: return launch_sep_fwd<5, POST, RESID>(a, op->sep, s);
+    case 6: return launch_sep_fwd<6, POST, RESID>(a, op->sep, s);
+    case 7: return launch_sep_fwd<7, POST, RESID>(a, op->sep, s);
+    case 8: return launch_sep_fwd<8, POST, RESID>(a, op->sep, s);
     }
     return DPSX_EUNSUPPORTED;
 }
 
 template <int R4, bool EPI>
-static int launch_sep_adj(const BlurArgs &a, const SepTaps &t, int radius, bool vec, hipStream_t s)
+static int launch_sep_adj(const BlurArgs &a, const SepTaps &t, int reach, hipStream_t s)
 {
     const size_t lds = sep_lds_bytes(4 * R4);
-    if (vec) DPSX_LAUNCH((k_blur_sep_adj<R4, EPI, true>), grid_blocks(a), lds, s, a, t, radius);
-    DPSX_LAUNCH((k_blur_sep_adj<R4, EPI, false>), grid_blocks(a), lds, s, a, t, radius);
+    DPSX_LAUNCH((k_blur_sep_adj<R4, EPI>), grid_blocks(a), lds, s, a, t, reach);
 }
 
 template <bool EPI>
-static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, bool vec, hipStream_t s)
+static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 {
     SepTaps f{};  // adjoint of a correlation = correlation with the reversed taps
     const int rr = op->radius4;
@@ -614,14 +440,14 @@ static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, bool vec, hipS
         f.v[i] = op->sep.v[2 * rr - i];
     }
     switch (rr / 4) {
-    case 1: return launch_sep_adj<1, EPI>(a, f, op->reach, vec, s);
-    case 2: return launch_sep_adj<2, EPI>(a, f, op->reach, vec, s);
-    case 3: return launch_sep_adj<3, EPI>(a, f, op->reach, vec, s);
-    case 4: return launch_sep_adj<4, EPI>(a, f, op->reach, vec, s);
-    case 5: return launch_sep_adj<5, EPI>(a, f, op->reach, vec, s);
-    case 6: return launch_sep_adj<6, EPI>(a, f, op->reach, vec, s);
-    case 7: return launch_sep_adj<7, EPI>(a, f, op->reach, vec, s);
-    case 8: return launch_sep_adj<8, EPI>(a, f, op->reach, vec, s);
+    case 1: return launch_sep_adj<1, EPI>(a, f, op->reach, s);
+    case 2: return launch_sep_adj<2, EPI>(a, f, op->reach, s);
+    case 3: return launch_sep_adj<3, EPI>(a, f, op->reach, s);
+    case 4: return launch_sep_adj<4, EPI>(a, f, op->reach, s);
+    case 5: return launch_sep_adj<5, EPI>(a, f, op->reach, s);
+    case 6: return launch_sep_adj<6, EPI>(a, f, op->reach, s);
+    case 7: return launch_sep_adj<7, EPI>(a, f, op->reach, s);
+    case 8: return launch_sep_adj<8, EPI>(a, f, op->reach, s);
     }
     return DPSX_EUNSUPPORTED;
 }
@@ -671,8 +497,8 @@ int blur_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, in
     a.x = x; a.out = y;
     fill_geometry(a, planes, 1, h, w);
     const bool vec = vec_ok(h, w, {x, y});
-    return op->kind == OP_SEP ? dispatch_sep_fwd<false, false>(op, a, vec, s)
-                              : launch_taps_fwd<false, false>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_fwd<false, false>(op, a, s)
+                                     : launch_taps_fwd<false, false>(op, a, vec, s);
 }
 
 int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, hipStream_t s)
@@ -683,7 +509,7 @@ int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, in
     a.x = u; a.out = g;
     fill_geometry(a, planes, 1, h, w);
     const bool vec = vec_ok(h, w, {u, g});
-    return op->kind == OP_SEP ? dispatch_sep_adj<false>(op, a, vec, s) : launch_taps_adj<false>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_adj<false>(op, a, s) : launch_taps_adj<false>(op, a, vec, s);
 }
 
 int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
@@ -698,7 +524,7 @@ int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
     fill_geometry(a, f.n * f.c, f.c, f.h, f.w);
     const bool vec = vec_ok(f.h, f.w, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.y, f.resid}) &&
                      (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
-    return op->kind == OP_SEP ? dispatch_sep_fwd<true, true>(op, a, vec, s) : launch_taps_fwd<true, true>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_fwd<true, true>(op, a, s) : launch_taps_fwd<true, true>(op, a, vec, s);
 }
 
 int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
@@ -712,7 +538,7 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
     a.k = b.k;
     fill_geometry(a, b.n * b.c, b.c, b.h, b.w);
     const bool vec = vec_ok(b.h, b.w, {b.resid, b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
-    return op->kind == OP_SEP ? dispatch_sep_adj<true>(op, a, vec, s) : launch_taps_adj<true>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_adj<true>(op, a, s) : launch_taps_adj<true>(op, a, vec, s);
 }
 
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,
@@ -724,7 +550,7 @@ int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, f
     a.x = x; a.y = y; a.y_n = (int)y_n; a.out = nullptr; a.partials = partials;
     fill_geometry(a, n * c, c, h, w);
     const bool vec = vec_ok(h, w, {x, y});
-    return op->kind == OP_SEP ? dispatch_sep_fwd<false, true>(op, a, vec, s) : launch_taps_fwd<false, true>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_fwd<false, true>(op, a, s) : launch_taps_fwd<false, true>(op, a, vec, s);
 }
 
 }  // namespace dpsx

@@ -1,0 +1,385 @@
+// Separable blur kernels (included by blur.hip after BlurArgs / epilogue helpers).
+//
+// RR = tap reach rounded up to a multiple of 4 (<= 32); taps centred at index RR.
+// One LDS image s[RH][SW] per block (RH = 64 + 2RR rows, SW = 64 + 2RR + pad floats):
+//   1. loader: every thread first ISSUES all of its global loads (4 interior float4 units x up to
+//      4 streams + up to 4 halo units x 2 streams = up to 24 x 16 B in flight per lane, ~96 KiB per
+//      block), then computes x0_hat and fills LDS -- the kernel lives on memory-level parallelism;
+//   2. horizontal pass IN PLACE: the 8 items of a row sit in one wave, which reads its windows
+//      (registers) before it writes the 64 outputs over the row's first 64 words, so no second LDS
+//      buffer is needed and four blocks fit a CU;
+//   3. vertical pass LDS -> registers, 4 x 4 outputs per thread, fused epilogue.
+// The adjoint adds the reflection fold: padded positions -j and 2(n-1)-j also land on pixel j, which
+// is a (reach x reach) triangular product per border row / column, done on border tiles only.
+
+// Padded positions other than i itself that ReflectionPad maps onto image index i
+// (axis length n, taps reaching R < n): -i for 1 <= i <= R, and 2(n-1)-i for n-1-R <= i <= n-2.
+__device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
+{
+    int cnt = 0;
+    p[0] = p[1] = 0;
+    if (i >= 1 && i <= R) p[cnt++] = -i;
+    if (i <= n - 2 && i >= n - 1 - R) p[cnt++] = 2 * (n - 1) - i;
+    return cnt;
+}
+
+template <int RR>
+struct SepGeom {
+    static constexpr int RH = TH + 2 * RR;
+    static constexpr int RW = TW + 2 * RR;
+    static constexpr int SW = (RW + 4 + 15) / 16 * 16;  // multiple of 16 floats: conflict-free vertical float4 reads
+    static constexpr int RWU = RW / 4;             // float4 units per region row
+    static constexpr int HALO_TB = RR * RWU;       // units in the top (or bottom) halo band
+    static constexpr int HALO_LR = TH * (RR / 4);  // units in the left (or right) halo band
+    static constexpr int HALO = 2 * HALO_TB + 2 * HALO_LR;
+    static constexpr int HALO_PER_THREAD = (HALO + NT - 1) / NT;
+    static constexpr int FOLD_PER_THREAD = (RH * 2 * RR + NT - 1) / NT;
+};
+
+template <int RR>
+__device__ __forceinline__ void halo_unit(int hu, int &rr, int &cu)
+{
+    using G = SepGeom<RR>;
+    if (hu < G::HALO_TB) {
+        rr = hu / G::RWU;
+        cu = hu - rr * G::RWU;
+    } else if (hu < 2 * G::HALO_TB) {
+        hu -= G::HALO_TB;
+        rr = hu / G::RWU;
+        cu = hu - rr * G::RWU;
+        rr += TH + RR;
+    } else if (hu < 2 * G::HALO_TB + G::HALO_LR) {
+        hu -= 2 * G::HALO_TB;
+        rr = hu / (RR / 4);
+        cu = hu - rr * (RR / 4);
+        rr += RR;
+    } else {
+        hu -= 2 * G::HALO_TB + G::HALO_LR;
+        rr = hu / (RR / 4);
+        cu = hu - rr * (RR / 4) + (RR + TW) / 4;
+        rr += RR;
+    }
+}
+
+// load one float4 unit of a plane at image row gy (already mapped), columns gx..gx+3
+template <bool REFLECT>
+__device__ __forceinline__ float4 load_unit(const float *plane, int sy, int gx, int w, bool rowok)
+{
+    if (!rowok) return make_float4(0, 0, 0, 0);
+    if (gx >= 0 && gx + 3 < w) return *reinterpret_cast<const float4 *>(plane + (int64_t)sy * w + gx);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int sx = gx + e;
+        bool ok = true;
+        if constexpr (REFLECT) sx = clampi(reflect_idx(sx, w), 0, w - 1);
+        else ok = sx >= 0 && sx < w;
+        v[e] = ok ? plane[(int64_t)sy * w + sx] : 0.0f;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int RR, bool POST, bool REFLECT>
+__device__ __forceinline__ void load_region_fast(float *s, const int h0, const int w0, const BlurArgs &a,
+                                                 const int plane)
+{
+    using G = SepGeom<RR>;
+    const int h = a.h, w = a.w;
+    const int64_t hw = (int64_t)h * w;
+    const int n = plane / a.c, ch = plane % a.c;
+    const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+    if constexpr (POST) {
+        src = a.x_t + (int64_t)plane * hw;
+        eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * hw;
+        vv = eps + (int64_t)a.c * hw;
+        zz = a.noise + (int64_t)plane * hw;
+    } else {
+        src = a.x + (int64_t)plane * hw;
+    }
+    constexpr int NI = TH * TW / 4 / NT;  // interior units per thread (4)
+    constexpr int NH = G::HALO_PER_THREAD;
+    float4 xi[NI], ei[NI], vi[NI], zi[NI], xh[NH], eh[NH];
+    int hrr[NH], hcu[NH];
+    // ---- issue every load first
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+        const int gy = h0 + row, gx = w0 + 4 * cu;
+        const bool inimg = gy < h && gx < w;
+        int sy = gy;
+        // a partial tile's rows past the image are part of the reflected halo of its last valid rows
+        if constexpr (REFLECT) sy = clampi(reflect_idx(gy, h), 0, h - 1);
+        xi[k] = load_unit<REFLECT>(src, sy, gx, w, REFLECT || inimg);
+        if constexpr (POST) {
+            ei[k] = load_unit<true>(eps, sy, gx, w, true);
+            vi[k] = zi[k] = make_float4(0, 0, 0, 0);
+            if (inimg && a.k.add_noise) {
+                vi[k] = *reinterpret_cast<const float4 *>(vv + (int64_t)gy * w + gx);
+                zi[k] = *reinterpret_cast<const float4 *>(zz + (int64_t)gy * w + gx);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const int hu = threadIdx.x + k * NT;
+        xh[k] = make_float4(0, 0, 0, 0);
+        if constexpr (POST) eh[k] = xh[k];
+        hrr[k] = -1;
+        if (hu < G::HALO) {
+            halo_unit<RR>(hu, hrr[k], hcu[k]);
+            const int gy = h0 - RR + hrr[k], gx = w0 - RR + 4 * hcu[k];
+            int sy = gy;
+            bool rowok = true;
+            if constexpr (REFLECT) sy = clampi(reflect_idx(gy, h), 0, h - 1);
+            else rowok = gy >= 0 && gy < h;
+            xh[k] = load_unit<REFLECT>(src, sy, gx, w, rowok);
+            if constexpr (POST) eh[k] = load_unit<true>(eps, sy, gx, w, true);
+        }
+    }
+    // ---- interior: S1 outputs + LDS
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+        float4 val = xi[k];
+        if constexpr (POST) {
+            const int gy = h0 + row, gx = w0 + 4 * cu;
+            bool b0, b1, b2, b3;
+            float4 x0;
+            x0.x = post_x0(xi[k].x, ei[k].x, a.k, b0);
+            x0.y = post_x0(xi[k].y, ei[k].y, a.k, b1);
+            x0.z = post_x0(xi[k].z, ei[k].z, a.k, b2);
+            x0.w = post_x0(xi[k].w, ei[k].w, a.k, b3);
+            if (gy < h && gx < w) {
+                float4 sm;
+                sm.x = post_sample(xi[k].x, x0.x, vi[k].x, zi[k].x, a.k);
+                sm.y = post_sample(xi[k].y, x0.y, vi[k].y, zi[k].y, a.k);
+                sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
+                sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
+                const int64_t o = (int64_t)plane * hw + (int64_t)gy * w + gx;
+                *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+                *reinterpret_cast<float4 *>(a.sample + o) = sm;
+                *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
+            }
+            val = x0;
+        }
+        *reinterpret_cast<float4 *>(s + (RR + row) * G::SW + RR + 4 * cu) = val;
+    }
+    // ---- halo: x0_hat recomputed from the neighbours' x_t / eps (served by L2)
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        if (hrr[k] < 0) continue;
+        float4 val = xh[k];
+        if constexpr (POST) {
+            bool b;
+            val.x = post_x0(xh[k].x, eh[k].x, a.k, b);
+            val.y = post_x0(xh[k].y, eh[k].y, a.k, b);
+            val.z = post_x0(xh[k].z, eh[k].z, a.k, b);
+            val.w = post_x0(xh[k].w, eh[k].w, a.k, b);
+        }
+        *reinterpret_cast<float4 *>(s + hrr[k] * G::SW + 4 * hcu[k]) = val;
+    }
+}
+
+// in-place horizontal pass over all RH rows: out[c] = sum_d taps[d] * in[c + d], c in [0, 64)
+template <int RR>
+__device__ __forceinline__ void hpass_inplace(float *s, const float (&taps)[2 * kMaxRadius + 1])
+{
+    using G = SepGeom<RR>;
+    constexpr int NG = TW / 8, NF = (8 + 2 * RR) / 4;
+    for (int it = threadIdx.x; it < G::RH * NG; it += NT) {
+        const int rr = it / NG, g = it - rr * NG;   // the 8 items of a row are 8 consecutive lanes of one wave
+        float *row = s + rr * G::SW + g * 8;
+        float4 win[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) win[j] = *reinterpret_cast<const float4 *>(row + 4 * j);
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float v[4] = {win[j].x, win[j].y, win[j].z, win[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const int d = 4 * j + e - o;
+                    if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], v[e], acc[o]);
+                }
+        }
+        // all reads of this wave's rows are in registers before the first write issues (SIMD lockstep)
+        *reinterpret_cast<float4 *>(row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(row + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// vertical pass: rows 4rg..4rg+3, columns 4cg..4cg+3 of the tile from the row-convolved image
+template <int RR>
+__device__ __forceinline__ void vpass_regs(const float *s, float (&acc)[4][4], const int rg, const int cg,
+                                           const float (&taps)[2 * kMaxRadius + 1])
+{
+    using G = SepGeom<RR>;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4 + 2 * RR; ++j) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(s + (4 * rg + j) * G::SW + 4 * cg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = j - i;
+            if (d >= 0 && d <= 2 * RR) {
+                acc[i][0] = fmaf(taps[d], v4.x, acc[i][0]);
+                acc[i][1] = fmaf(taps[d], v4.y, acc[i][1]);
+                acc[i][2] = fmaf(taps[d], v4.z, acc[i][2]);
+                acc[i][3] = fmaf(taps[d], v4.w, acc[i][3]);
+            }
+        }
+    }
+}
+
+template <int R4, bool POST, bool RESID>
+__global__ __launch_bounds__(NT) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
+{
+    constexpr int RR = 4 * R4;
+    using G = SepGeom<RR>;
+    extern __shared__ __align__(16) float lds[];
+    float *s = lds, *s_red = lds + G::RH * G::SW;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    if (!(a.dbg & 4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
+    else for (int i = threadIdx.x; i < G::RH * G::SW; i += NT) s[i] = (float)i;
+    __syncthreads();
+    if (!(a.dbg & 1)) hpass_inplace<RR>(s, taps.h);
+    __syncthreads();
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float acc[4][4];
+    if (!(a.dbg & 2)) vpass_regs<RR>(s, acc, rg, cg, taps.v);
+    else for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e];
+    const int ox = w0 + 4 * cg;
+    float ss = 0.0f;
+    if (ox < a.w && !(a.dbg & 8)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = h0 + 4 * rg + i;
+            if constexpr (RESID) ss += resid_epilogue<true>(a, plane, oy, ox, acc[i]);
+            else out_epilogue<true>(a, plane, oy, ox, acc[i], 0.0f, false);
+        }
+    }
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+    }
+}
+
+// Adjoint.  taps are the REVERSED taps f[d] = k[2RR - d]:  G[p] = sum_d f[d] * u_z[p + d - RR]  is the
+// correlation-transpose on the zero-extended cotangent; the reflection fold adds, for a pixel at
+// distance j in [1, R] from the left/top edge,   sum_{m=0}^{R-j} f[RR + j + m] * U[m]
+// and at distance j from the right/bottom edge   sum_{m=0}^{R-j} f[RR - j - m] * U[n-1-m]   (R = tap reach).
+template <int R4, bool EPI>
+__global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, int reach)
+{
+    constexpr int RR = 4 * R4;
+    using G = SepGeom<RR>;
+    extern __shared__ __align__(16) float lds[];
+    float *s = lds, *s_th = lds + G::RH * G::SW, *s_tv = s_th + 80;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    float coef = 0.0f;
+    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
+    const bool lfold = w0 == 0, rfold = w0 + TW >= a.w - 1 - reach;       // block-uniform
+    const bool tfold = h0 == 0, bfold = h0 + TH >= a.h - 1 - reach;
+    const bool wfold = reach > 0 && (lfold || rfold), hfold = reach > 0 && (tfold || bfold);
+    if (wfold || hfold)
+        for (int i = threadIdx.x; i <= 2 * RR; i += NT) {
+            s_th[i] = taps.h[i];
+            s_tv[i] = taps.v[i];
+        }
+    load_region_fast<RR, false, false>(s, h0, w0, a, plane);
+    __syncthreads();
+    // ---- horizontal fold terms from the untouched cotangent, kept in registers across the in-place pass
+    // item (row, q): q < reach -> pixel column 1 + q (left list); else pixel (w-2) - (q - reach) (right list).
+    // A column within `reach` of BOTH edges (tiny images) is owned by its left-list item, which then
+    // also carries the right-edge term, so every LDS word has exactly one writer.
+    float fold[G::FOLD_PER_THREAD];
+    int fold_col[G::FOLD_PER_THREAD];
+    if (wfold) {
+#pragma unroll
+        for (int k = 0; k < G::FOLD_PER_THREAD; ++k) {
+            fold[k] = 0.0f;
+            fold_col[k] = -1;
+            const int it = threadIdx.x + k * NT;
+            if (it >= G::RH * 2 * reach) continue;
+            const int rr = it / (2 * reach), q = it - rr * 2 * reach;
+            const int j = q < reach ? 1 + q : (a.w - 2) - (q - reach);   // image column
+            if (j < w0 || j >= w0 + TW || j < 0 || j >= a.w) continue;
+            if (q >= reach && j >= 1 && j <= reach) continue;            // owned by the left list
+            const float *row = s + rr * G::SW;
+            float add = 0.0f;
+            if (j >= 1 && j <= reach)                                    // distance j from the left edge
+                for (int m = 0; m <= reach - j; ++m) {
+                    const int col = m - (w0 - RR);
+                    if (col >= 0 && col < G::RW) add = fmaf(s_th[RR + j + m], row[col], add);
+                }
+            const int jr = a.w - 1 - j;                                  // distance from the right edge
+            if (jr >= 1 && jr <= reach)
+                for (int m = 0; m <= reach - jr; ++m) {
+                    const int col = (a.w - 1 - m) - (w0 - RR);
+                    if (col >= 0 && col < G::RW) add = fmaf(s_th[RR - jr - m], row[col], add);
+                }
+            fold[k] = add;
+            fold_col[k] = rr * G::SW + (j - w0);
+        }
+        __syncthreads();
+    }
+    hpass_inplace<RR>(s, taps.h);
+    __syncthreads();
+    if (wfold) {
+#pragma unroll
+        for (int k = 0; k < G::FOLD_PER_THREAD; ++k)
+            if (fold_col[k] >= 0) s[fold_col[k]] += fold[k];
+        __syncthreads();
+    }
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float acc[4][4];
+    vpass_regs<RR>(s, acc, rg, cg, taps.v);
+    if (hfold) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = h0 + 4 * rg + i;
+            if (oy >= a.h) continue;
+            if (oy >= 1 && oy <= reach) {                      // top edge
+                for (int m = 0; m <= reach - oy; ++m) {
+                    const int row = m - (h0 - RR);
+                    if (row < 0 || row >= G::RH) continue;
+                    const float4 v4 = *reinterpret_cast<const float4 *>(s + row * G::SW + 4 * cg);
+                    const float t = s_tv[RR + oy + m];
+                    acc[i][0] = fmaf(t, v4.x, acc[i][0]);
+                    acc[i][1] = fmaf(t, v4.y, acc[i][1]);
+                    acc[i][2] = fmaf(t, v4.z, acc[i][2]);
+                    acc[i][3] = fmaf(t, v4.w, acc[i][3]);
+                }
+            }
+            const int jb = a.h - 1 - oy;                       // distance from the bottom edge
+            if (jb >= 1 && jb <= reach) {
+                for (int m = 0; m <= reach - jb; ++m) {
+                    const int row = (a.h - 1 - m) - (h0 - RR);
+                    if (row < 0 || row >= G::RH) continue;
+                    const float4 v4 = *reinterpret_cast<const float4 *>(s + row * G::SW + 4 * cg);
+                    const float t = s_tv[RR - jb - m];
+                    acc[i][0] = fmaf(t, v4.x, acc[i][0]);
+                    acc[i][1] = fmaf(t, v4.y, acc[i][1]);
+                    acc[i][2] = fmaf(t, v4.z, acc[i][2]);
+                    acc[i][3] = fmaf(t, v4.w, acc[i][3]);
+                }
+            }
+        }
+    }
+    const int ox = w0 + 4 * cg;
+    if (ox < a.w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
+    }
+}

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench: time each launch of the fused DPS step (and the plain operator calls) in isolation.
+
+    python tools/kbench.py [--operator gaussian_blur] [--particles 64] [--reps 30] [--only fwd,bwd,upd,op,adj]
+
+Prints one line per launch: avg / min microseconds and achieved GB/s against the algorithmic bytes
+(SURVEY.md 8d).  Used under rocprofv3 for the per-kernel profiles in profiles/.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--operator", default="gaussian_blur")
+    ap.add_argument("--particles", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--only", default="fwd,bwd,upd,op,adj,score")
+    args = ap.parse_args()
+    from dps_ttc_amd import kernels
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    dev = torch.device("cuda", 0)
+    n = args.particles
+    op, fkw = bench.build_operator(args.operator, dev)
+    smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="")
+    x_t, ring, truth, meas_noise = bench.synth_inputs(n, 2, dev, 1234)
+    yy = op.forward(truth.to(dev), **fkw).detach()
+    y = (yy + meas_noise.to(dev)[..., :yy.shape[-2], :yy.shape[-1]]).contiguous()
+    handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
+    buf = kernels.StepBuffers(handle, n, 3, 256, 256, dev)
+    ck = smp.step_coefs[500]
+    rho = y[0].numel() / x_t[0].numel()
+    P = bench.P_BYTES
+    u = torch.randn((n,) + tuple(y.shape[1:]), device=dev)
+    cases = {
+        "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck),
+                (7 + rho) * P),
+        "bwd": (lambda i: kernels.step_bwd(handle, buf, y, 0.3, 1, ck), (4 + rho) * P),
+        "upd": (lambda i: kernels.step_update(buf, ring[i % 2]["g_unet"], ck), 4 * P),
+        "op": (lambda i: handle.forward(x_t), (1 + rho) * P),
+        "adj": (lambda i: handle.adjoint(u, x=x_t, in_hw=(256, 256)), (1 + rho) * P),
+        "score": (lambda i: handle.score(x_t, y), 1 * P),
+    }
+    for name in args.only.split(","):
+        fn, bytes_pp = cases[name]
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            fn(i)
+            b.record()
+        torch.cuda.synchronize()
+        ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+        print(f"{name:6s} avg {ts.mean():8.1f} us  min {ts.min():8.1f} us   "
+              f"{bytes_pp * n / ts.mean() / 1e3:8.1f} GB/s algorithmic ({bytes_pp / P:.2f} P/particle)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,7 @@ struct SepGeom {
     static constexpr int RH = TH + 2 * RR;
     static constexpr int RW = TW + 2 * RR;
     static constexpr int SW = (RW + 4 + 15) / 16 * 16;  // multiple of 16 floats: conflict-free vertical float4 reads
+    static constexpr int DW = (SW - TW) / 4 * 4;   // words per row the in-place horizontal pass leaves dead
     static constexpr int RWU = RW / 4;             // float4 units per region row
     static constexpr int HALO_TB = RR * RWU;       // units in the top (or bottom) halo band
     static constexpr int HALO_LR = TH * (RR / 4);  // units in the left (or right) halo band
@@ -180,30 +181,71 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
     }
 }
 
-// in-place horizontal pass over all RH rows: out[c] = sum_d taps[d] * in[c + d], c in [0, 64)
-template <int RR>
+// in-place horizontal pass over all RH rows: out[c] = sum_d taps[d] * in[c + d], c in [0, 64).
+// FOLD (adjoint only; taps are then the reversed taps f): 1 = this tile owns the image's left edge,
+// 2 = it is a full-width tile owning the right edge.  The fold term of output column j needs only
+// cotangent columns that already sit in the lane's register window, so it costs extra FMAs in the two
+// or so lanes per row whose outputs lie within RR of the edge -- no barrier, no extra LDS traffic.
+template <int RR, int FOLD = 0>
 __device__ __forceinline__ void hpass_inplace(float *s, const float (&taps)[2 * kMaxRadius + 1])
 {
     using G = SepGeom<RR>;
-    constexpr int NG = TW / 8, NF = (8 + 2 * RR) / 4;
+    constexpr int NG = TW / 8, NF = (8 + 2 * RR) / 4, WN = 8 + 2 * RR;
     for (int it = threadIdx.x; it < G::RH * NG; it += NT) {
         const int rr = it / NG, g = it - rr * NG;   // the 8 items of a row are 8 consecutive lanes of one wave
         float *row = s + rr * G::SW + g * 8;
-        float4 win[NF];
+        float win[WN];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) win[j] = *reinterpret_cast<const float4 *>(row + 4 * j);
+        for (int j = 0; j < NF; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 4 * j);
+            win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+        }
         float acc[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const float v[4] = {win[j].x, win[j].y, win[j].z, win[j].w};
+        for (int k = 0; k < WN; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int o = 0; o < 8; ++o) {
+                const int d = k - o;
+                if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], win[k], acc[o]);
+            }
+        if constexpr (FOLD == 1) {
+            // pixel column j = 8 GG + o at distance j from the left edge: += sum_m f[RR+j+m] * U[m],
+            // U[m] = region column RR + m = window element RR + m - 8 GG
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    const int d = 4 * j + e - o;
-                    if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], v[e], acc[o]);
+            for (int GG = 0; GG <= RR / 8; ++GG)
+                if (g == GG) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        const int j = 8 * GG + o;
+                        if (j >= 1 && j <= RR) {
+#pragma unroll
+                            for (int m = 0; m <= RR - j; ++m) {
+                                const int k = RR + m - 8 * GG;
+                                if (k >= 0 && k < WN) acc[o] = fmaf(taps[RR + j + m], win[k], acc[o]);
+                            }
+                        }
+                    }
+                }
+        }
+        if constexpr (FOLD == 2) {
+            // tile column c = 8 GG + o at distance j = TW-1-c from the right edge: += sum_m f[RR-j-m] * U[m],
+            // U[m] = image column w-1-m = region column TW-1-m+RR = window element TW-1-m+RR - 8 GG
+#pragma unroll
+            for (int GG = (TW - 1 - RR) / 8; GG < NG; ++GG)
+                if (g == GG) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        const int j = TW - 1 - (8 * GG + o);
+                        if (j >= 1 && j <= RR) {
+#pragma unroll
+                            for (int m = 0; m <= RR - j; ++m) {
+                                const int k = TW - 1 - m + RR - 8 * GG;
+                                if (k >= 0 && k < WN) acc[o] = fmaf(taps[RR - j - m], win[k], acc[o]);
+                            }
+                        }
+                    }
                 }
         }
         // all reads of this wave's rows are in registers before the first write issues (SIMD lockstep)
@@ -212,8 +254,10 @@ __device__ __forceinline__ void hpass_inplace(float *s, const float (&taps)[2 * 
     }
 }
 
-// vertical pass: rows 4rg..4rg+3, columns 4cg..4cg+3 of the tile from the row-convolved image
-template <int RR>
+// vertical pass: rows 4rg..4rg+3, columns 4cg..4cg+3 of the tile from the row-convolved image.
+// FOLD (adjoint): 1 = tile owns the image's top edge, 2 = full-height tile owning the bottom edge; the
+// fold term of an output row within RR of the edge re-reads at most RR rows of the same four columns.
+template <int RR, int FOLD = 0>
 __device__ __forceinline__ void vpass_regs(const float *s, float (&acc)[4][4], const int rg, const int cg,
                                            const float (&taps)[2 * kMaxRadius + 1])
 {
@@ -236,10 +280,57 @@ __device__ __forceinline__ void vpass_regs(const float *s, float (&acc)[4][4], c
             }
         }
     }
+    if constexpr (FOLD == 1) {
+        // output row oy = 4 RG + i at distance oy from the top: += sum_m f[RR+oy+m] * T[m], T[m] = region row RR+m
+        if (rg <= RR / 4) {
+#pragma unroll
+            for (int RG = 0; RG <= RR / 4; ++RG)
+                if (rg == RG) {
+#pragma unroll
+                    for (int m = 0; m < RR; ++m) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(s + (RR + m) * G::SW + 4 * cg);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int oy = 4 * RG + i;
+                            if (oy >= 1 && oy <= RR && m <= RR - oy) {
+                                acc[i][0] = fmaf(taps[RR + oy + m], v4.x, acc[i][0]);
+                                acc[i][1] = fmaf(taps[RR + oy + m], v4.y, acc[i][1]);
+                                acc[i][2] = fmaf(taps[RR + oy + m], v4.z, acc[i][2]);
+                                acc[i][3] = fmaf(taps[RR + oy + m], v4.w, acc[i][3]);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    if constexpr (FOLD == 2) {
+        // output row 4 RG + i at distance jb = TH-1-(4 RG + i) from the bottom: += sum_m f[RR-jb-m] * T[m],
+        // T[m] = image row h-1-m = region row TH-1-m+RR
+        if (rg >= (TH - 1 - RR) / 4) {
+#pragma unroll
+            for (int RG = (TH - 1 - RR) / 4; RG < TH / 4; ++RG)
+                if (rg == RG) {
+#pragma unroll
+                    for (int m = 0; m < RR; ++m) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(s + (TH - 1 - m + RR) * G::SW + 4 * cg);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int jb = TH - 1 - (4 * RG + i);
+                            if (jb >= 1 && jb <= RR && m <= RR - jb) {
+                                acc[i][0] = fmaf(taps[RR - jb - m], v4.x, acc[i][0]);
+                                acc[i][1] = fmaf(taps[RR - jb - m], v4.y, acc[i][1]);
+                                acc[i][2] = fmaf(taps[RR - jb - m], v4.z, acc[i][2]);
+                                acc[i][3] = fmaf(taps[RR - jb - m], v4.w, acc[i][3]);
+                            }
+                        }
+                    }
+                }
+        }
+    }
 }
 
 template <int R4, bool POST, bool RESID>
-__global__ __launch_bounds__(NT) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
+__global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
 {
     constexpr int RR = 4 * R4;
     using G = SepGeom<RR>;
@@ -276,9 +367,17 @@ __global__ __launch_bounds__(NT) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
 // Adjoint.  taps are the REVERSED taps f[d] = k[2RR - d]:  G[p] = sum_d f[d] * u_z[p + d - RR]  is the
 // correlation-transpose on the zero-extended cotangent; the reflection fold adds, for a pixel at
 // distance j in [1, R] from the left/top edge,   sum_{m=0}^{R-j} f[RR + j + m] * U[m]
-// and at distance j from the right/bottom edge   sum_{m=0}^{R-j} f[RR - j - m] * U[n-1-m]   (R = tap reach).
+// and at distance j from the right/bottom edge   sum_{m=0}^{R-j} f[RR - j - m] * U[n-1-m]   (R = tap reach;
+// taps beyond the reach are zero, so the loops below run to the compile-time RR with SGPR taps).
+//
+// Fast folds (tiles touching exactly one border per axis and holding all RR fold targets -- every border
+// tile of a 256x256 image): one thread per row computes the RR horizontal terms from the untouched cotangent
+// before the in-place pass and adds them as float4 afterwards; one thread per column computes the RR vertical
+// terms into LDS words the horizontal pass left dead (columns 64.. of rows 0..2RR-1).  Other geometries
+// (tiny or ragged images) take the generic slow folds.
+
 template <int R4, bool EPI>
-__global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, int reach)
+__global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps, int reach)
 {
     constexpr int RR = 4 * R4;
     using G = SepGeom<RR>;
@@ -289,23 +388,28 @@ __global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, i
     const int h0 = ty * TH, w0 = tx * TW;
     float coef = 0.0f;
     if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
-    const bool lfold = w0 == 0, rfold = w0 + TW >= a.w - 1 - reach;       // block-uniform
-    const bool tfold = h0 == 0, bfold = h0 + TH >= a.h - 1 - reach;
-    const bool wfold = reach > 0 && (lfold || rfold), hfold = reach > 0 && (tfold || bfold);
-    if (wfold || hfold)
+    // ---- which folds does this tile need (all block-uniform)
+    const bool lfold = reach > 0 && w0 == 0, rfold = reach > 0 && w0 + TW >= a.w - 1 - reach;
+    const bool tfold = reach > 0 && h0 == 0, bfold = reach > 0 && h0 + TH >= a.h - 1 - reach;
+    const bool last_x = w0 + TW >= a.w, last_y = h0 + TH >= a.h;
+    const bool wfast = (lfold != rfold) && (lfold ? a.w >= RR + 1 : (last_x && a.w - w0 == TW));
+    const bool hfast = (tfold != bfold) && (tfold ? a.h >= RR + 1 : (last_y && a.h - h0 == TH));
+    const bool wslow = (lfold || rfold) && !wfast && !(a.dbg & 16), hslow = (tfold || bfold) && !hfast && !(a.dbg & 16);
+    const bool wfast_ = wfast && !(a.dbg & 32), hfast_ = hfast && !(a.dbg & 32);
+    if (wslow || hslow)
         for (int i = threadIdx.x; i <= 2 * RR; i += NT) {
             s_th[i] = taps.h[i];
             s_tv[i] = taps.v[i];
         }
-    load_region_fast<RR, false, false>(s, h0, w0, a, plane);
+    if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
     __syncthreads();
     // ---- horizontal fold terms from the untouched cotangent, kept in registers across the in-place pass
-    // item (row, q): q < reach -> pixel column 1 + q (left list); else pixel (w-2) - (q - reach) (right list).
-    // A column within `reach` of BOTH edges (tiny images) is owned by its left-list item, which then
-    // also carries the right-edge term, so every LDS word has exactly one writer.
     float fold[G::FOLD_PER_THREAD];
     int fold_col[G::FOLD_PER_THREAD];
-    if (wfold) {
+    if (wslow) {
+        // item (row, q): q < reach -> pixel column 1 + q (left list); else pixel (w-2) - (q - reach) (right
+        // list).  A column within `reach` of BOTH edges is owned by its left-list item, which then also
+        // carries the right-edge term, so every LDS word has exactly one writer.
 #pragma unroll
         for (int k = 0; k < G::FOLD_PER_THREAD; ++k) {
             fold[k] = 0.0f;
@@ -318,12 +422,12 @@ __global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, i
             if (q >= reach && j >= 1 && j <= reach) continue;            // owned by the left list
             const float *row = s + rr * G::SW;
             float add = 0.0f;
-            if (j >= 1 && j <= reach)                                    // distance j from the left edge
+            if (j >= 1 && j <= reach)
                 for (int m = 0; m <= reach - j; ++m) {
                     const int col = m - (w0 - RR);
                     if (col >= 0 && col < G::RW) add = fmaf(s_th[RR + j + m], row[col], add);
                 }
-            const int jr = a.w - 1 - j;                                  // distance from the right edge
+            const int jr = a.w - 1 - j;
             if (jr >= 1 && jr <= reach)
                 for (int m = 0; m <= reach - jr; ++m) {
                     const int col = (a.w - 1 - m) - (w0 - RR);
@@ -334,9 +438,12 @@ __global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, i
         }
         __syncthreads();
     }
-    hpass_inplace<RR>(s, taps.h);
+    if (a.dbg & 1) {}
+    else if (wfast_ && lfold) hpass_inplace<RR, 1>(s, taps.h);
+    else if (wfast_) hpass_inplace<RR, 2>(s, taps.h);
+    else hpass_inplace<RR, 0>(s, taps.h);
     __syncthreads();
-    if (wfold) {
+    if (wslow) {
 #pragma unroll
         for (int k = 0; k < G::FOLD_PER_THREAD; ++k)
             if (fold_col[k] >= 0) s[fold_col[k]] += fold[k];
@@ -344,8 +451,11 @@ __global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, i
     }
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     float acc[4][4];
-    vpass_regs<RR>(s, acc, rg, cg, taps.v);
-    if (hfold) {
+    if (a.dbg & 2) { for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e]; }
+    else if (hfast_ && tfold) vpass_regs<RR, 1>(s, acc, rg, cg, taps.v);
+    else if (hfast_) vpass_regs<RR, 2>(s, acc, rg, cg, taps.v);
+    else vpass_regs<RR, 0>(s, acc, rg, cg, taps.v);
+    if (hslow) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = h0 + 4 * rg + i;
@@ -378,7 +488,7 @@ __global__ __launch_bounds__(NT) void k_blur_sep_adj(BlurArgs a, SepTaps taps, i
         }
     }
     const int ox = w0 + 4 * cg;
-    if (ox < a.w) {
+    if (ox < a.w && !(a.dbg & 8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
     }

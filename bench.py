@@ -209,12 +209,14 @@ def main():
 def cpu_baseline(args, smp, ring, x_t, y, handle, device):
     """The oracle (plain-C port of the reference step, OpenMP) on the host cores, same inputs, bounded sample.
     Also yields the parity figure of the metric: rel-L2 of the HIP x0_hat / x_{t-1} against it."""
+    # threads = the cores this process may actually run on (the GPU box gives a CPU share, not the host)
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(cores)      # read by libgomp when the oracle library loads
     import oracle
     from dps_ttc_amd import kernels
     nc, steps = min(args.cpu_particles, x_t.shape[0]), args.cpu_steps
     orc = oracle.make_operator("gaussian_blur", kernel_size=61, intensity=3.0)
     sched = oracle.tables.schedule(1000)
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     x = x_t[:nc].cpu().numpy()
     yh = y.cpu().numpy()
     sets = [{k: v[:nc].cpu().numpy() for k, v in s.items()} for s in ring]

@@ -210,7 +210,8 @@ def cpu_baseline(args, smp, ring, x_t, y, handle, device):
     """The oracle (plain-C port of the reference step, OpenMP) on the host cores, same inputs, bounded sample.
     Also yields the parity figure of the metric: rel-L2 of the HIP x0_hat / x_{t-1} against it."""
     # threads = the cores this process may actually run on (the GPU box gives a CPU share, not the host)
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
+    # (a 1-GPU box: 16 of the host's cores -- the affinity mask does not show the share, so cap at 16)
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(len(os.sched_getaffinity(0)), 16)
     os.environ["OMP_NUM_THREADS"] = str(cores)      # read by libgomp when the oracle library loads
     import oracle
     from dps_ttc_amd import kernels

@@ -38,6 +38,11 @@ struct ResizeDev {
     int ti;                   // input rows per block
     int adj_rows;             // max u rows staged per block
     const int *ablk_lo, *ablk_cnt;
+    int nnz_w;                // entries of the W inverse
+    int ell_w;                // ELL width: max entries of one input column
+    const int *ell_w_idx;     // [ell_w][in_w] output column (0 where padded)
+    const float *ell_w_w;     // [ell_w][in_w] weight (0 where padded)
+    int max_he;               // max H-inverse entries of one adjoint block
 };
 
 struct ResizeArgs {
@@ -74,7 +79,20 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     const int lo = d.blk_lo[blk], cnt = d.blk_cnt[blk];
     const int64_t ihw = (int64_t)d.in_h * d.in_w, ohw = (int64_t)d.out_h * d.out_w;
     const int n = plane / a.c, ch = plane % a.c;
-    // ---- stage A: rows [lo, lo+cnt) -> LDS
+    // ---- tables -> LDS (tiny; every lane then reads them at LDS speed instead of through L1)
+    float *s_ww = s_red + 16, *s_wh = s_ww + d.taps_w * d.out_w;
+    int *s_iw = reinterpret_cast<int *>(s_wh + d.taps_h * d.tp), *s_ih = s_iw + d.taps_w * d.out_w;
+    for (int i = threadIdx.x; i < d.taps_w * d.out_w; i += RT) {
+        s_ww[i] = d.w_w[i];
+        s_iw[i] = d.i_w[i];
+    }
+    const int p0 = blk * d.tp, p1 = min(d.out_h, p0 + d.tp);
+    for (int i = threadIdx.x; i < d.taps_h * d.tp; i += RT) {
+        const int k = i / d.tp, p = p0 + i % d.tp;
+        s_wh[i] = p < d.out_h ? d.w_h[k * d.out_h + p] : 0.0f;
+        s_ih[i] = p < d.out_h ? d.i_h[k * d.out_h + p] - lo : 0;
+    }
+    // ---- stage A: rows [lo, lo+cnt) -> LDS, four units per lane in flight before any is consumed
     {
         const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
         int olo = 0, ohi = 0;
@@ -88,64 +106,74 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
         } else {
             src = a.x + (int64_t)plane * ihw;
         }
-        constexpr int U = VEC ? 4 : 1;
-        const int wu = d.in_w / U;
-        for (int u = threadIdx.x; u < cnt * wu; u += RT) {
-            const int rr = u / wu, cu = u - rr * wu;
-            const int gy = lo + rr, gx = cu * U;
-            const int64_t o = (int64_t)gy * d.in_w + gx;
-            float val[U];
-            if constexpr (VEC) {
-                const float4 t = *reinterpret_cast<const float4 *>(src + o);
-                val[0] = t.x; val[1] = t.y; val[2] = t.z; val[3] = t.w;
-            } else {
-                val[0] = src[o];
-            }
-            if constexpr (POST) {
-                float ev[U], xin[U];
-                bool ins[U];
-                if constexpr (VEC) {
-                    const float4 q = *reinterpret_cast<const float4 *>(eps + o);
-                    ev[0] = q.x; ev[1] = q.y; ev[2] = q.z; ev[3] = q.w;
-                } else {
-                    ev[0] = eps[o];
-                }
+        constexpr int U = VEC ? 4 : 1, B = 4;
+        const int wu = d.in_w / U, total = cnt * wu;
+        for (int base = threadIdx.x; base < total; base += RT * B) {
+            float xv[B][U], ev[B][U], vq[B][U], zq[B][U];
 #pragma unroll
-                for (int e = 0; e < U; ++e) {
-                    xin[e] = val[e];
-                    val[e] = post_x0(xin[e], ev[e], a.k, ins[e]);
-                }
-                if (gy >= olo && gy < ohi) {
-                    float vq[U], zq[U], sm[U];
-                    if constexpr (VEC) {
+            for (int bb = 0; bb < B; ++bb) {
+                const int u = base + bb * RT;
+                if (u >= total) continue;
+                const int rr = u / wu, cu = u - rr * wu;
+                const int gy = lo + rr;
+                const int64_t o = (int64_t)gy * d.in_w + cu * U;
+                const bool own = POST && gy >= olo && gy < ohi && a.k.add_noise;
+                if constexpr (VEC) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src + o);
+                    xv[bb][0] = t.x; xv[bb][1] = t.y; xv[bb][2] = t.z; xv[bb][3] = t.w;
+                    if constexpr (POST) {
+                        const float4 q = *reinterpret_cast<const float4 *>(eps + o);
+                        ev[bb][0] = q.x; ev[bb][1] = q.y; ev[bb][2] = q.z; ev[bb][3] = q.w;
                         float4 t4 = make_float4(0, 0, 0, 0), z4 = t4;
-                        if (a.k.add_noise) {
+                        if (own) {
                             t4 = *reinterpret_cast<const float4 *>(vv + o);
                             z4 = *reinterpret_cast<const float4 *>(zz + o);
                         }
-                        vq[0] = t4.x; vq[1] = t4.y; vq[2] = t4.z; vq[3] = t4.w;
-                        zq[0] = z4.x; zq[1] = z4.y; zq[2] = z4.z; zq[3] = z4.w;
-                    } else {
-                        vq[0] = a.k.add_noise ? vv[o] : 0.0f;
-                        zq[0] = a.k.add_noise ? zz[o] : 0.0f;
+                        vq[bb][0] = t4.x; vq[bb][1] = t4.y; vq[bb][2] = t4.z; vq[bb][3] = t4.w;
+                        zq[bb][0] = z4.x; zq[bb][1] = z4.y; zq[bb][2] = z4.z; zq[bb][3] = z4.w;
                     }
-#pragma unroll
-                    for (int e = 0; e < U; ++e) sm[e] = post_sample(xin[e], val[e], vq[e], zq[e], a.k);
-                    const int64_t po = (int64_t)plane * ihw + o;
-                    if constexpr (VEC) {
-                        *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
-                        *reinterpret_cast<float4 *>(a.sample + po) = make_float4(sm[0], sm[1], sm[2], sm[3]);
-                        *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
-                    } else {
-                        a.x0_hat[po] = val[0];
-                        a.sample[po] = sm[0];
-                        a.inside_w[po] = ins[0];
+                } else {
+                    xv[bb][0] = src[o];
+                    if constexpr (POST) {
+                        ev[bb][0] = eps[o];
+                        vq[bb][0] = own ? vv[o] : 0.0f;
+                        zq[bb][0] = own ? zz[o] : 0.0f;
                     }
                 }
             }
-            float *dst = s_in + rr * d.in_w + gx;
-            if constexpr (VEC) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
-            else dst[0] = val[0];
+#pragma unroll
+            for (int bb = 0; bb < B; ++bb) {
+                const int u = base + bb * RT;
+                if (u >= total) continue;
+                const int rr = u / wu, cu = u - rr * wu;
+                const int gy = lo + rr, gx = cu * U;
+                float val[U];
+#pragma unroll
+                for (int e = 0; e < U; ++e) val[e] = xv[bb][e];
+                if constexpr (POST) {
+                    bool ins[U];
+#pragma unroll
+                    for (int e = 0; e < U; ++e) val[e] = post_x0(xv[bb][e], ev[bb][e], a.k, ins[e]);
+                    if (gy >= olo && gy < ohi) {
+                        float sm[U];
+#pragma unroll
+                        for (int e = 0; e < U; ++e) sm[e] = post_sample(xv[bb][e], val[e], vq[bb][e], zq[bb][e], a.k);
+                        const int64_t po = (int64_t)plane * ihw + (int64_t)gy * d.in_w + gx;
+                        if constexpr (VEC) {
+                            *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                            *reinterpret_cast<float4 *>(a.sample + po) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+                            *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
+                        } else {
+                            a.x0_hat[po] = val[0];
+                            a.sample[po] = sm[0];
+                            a.inside_w[po] = ins[0];
+                        }
+                    }
+                }
+                float *dst = s_in + rr * d.in_w + gx;
+                if constexpr (VEC) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+                else dst[0] = val[0];
+            }
         }
     }
     __syncthreads();
@@ -155,18 +183,17 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
         const float *row = s_in + rr * d.in_w;
         float acc = 0.0f;
         for (int k = 0; k < d.taps_w; ++k)
-            acc = fmaf(d.w_w[k * d.out_w + o], row[d.i_w[k * d.out_w + o]], acc);
+            acc = fmaf(s_ww[k * d.out_w + o], row[s_iw[k * d.out_w + o]], acc);
         s_tmp[rr * d.out_w + o] = acc;
     }
     __syncthreads();
     // ---- stage C: H pass  out[p][o] = sum_k w_h[k,p] * tmp[i_h[k,p] - lo][o]
     float ss = 0.0f;
-    const int p0 = blk * d.tp, p1 = min(d.out_h, p0 + d.tp);
     for (int it = threadIdx.x; it < (p1 - p0) * d.out_w; it += RT) {
-        const int p = p0 + it / d.out_w, o = it % d.out_w;
+        const int pl = it / d.out_w, p = p0 + pl, o = it % d.out_w;
         float acc = 0.0f;
         for (int k = 0; k < d.taps_h; ++k)
-            acc = fmaf(d.w_h[k * d.out_h + p], s_tmp[(d.i_h[k * d.out_h + p] - lo) * d.out_w + o], acc);
+            acc = fmaf(s_wh[k * d.tp + pl], s_tmp[s_ih[k * d.tp + pl] * d.out_w + o], acc);
         const int64_t oo = (int64_t)p * d.out_w + o;
         if constexpr (RESID) {
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
@@ -189,20 +216,34 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
 {
     extern __shared__ __align__(16) float lds[];
     float *s_u = lds, *s_t = lds + d.adj_rows * d.out_w;
+    const int elln = d.ell_w * d.in_w;
+    float *s_wv = s_t + d.ti * d.out_w, *s_hv = s_wv + elln;
+    int *s_wi = reinterpret_cast<int *>(s_hv + d.max_he), *s_hp = s_wi + elln, *s_hi = s_hp + d.ti + 1;
     const int nblk = (d.in_h + d.ti - 1) / d.ti;
     const int plane = blockIdx.x / nblk, blk = blockIdx.x % nblk;
     const int lo = d.ablk_lo[blk], cnt = d.ablk_cnt[blk];
     const int64_t ihw = (int64_t)d.in_h * d.in_w, ohw = (int64_t)d.out_h * d.out_w;
+    const int i0 = blk * d.ti, i1 = min(d.in_h, i0 + d.ti);
     const float *up = a.x + (int64_t)plane * ohw + (int64_t)lo * d.out_w;
     for (int u = threadIdx.x; u < cnt * d.out_w; u += RT) s_u[u] = up[u];
+    // inverse tables -> LDS: the whole W inverse, and the H-inverse rows of this block (rebased to 0)
+    for (int i = threadIdx.x; i < elln; i += RT) {      // [ell_w][in_w]: lane j reads word k*in_w + j, conflict-free
+        s_wi[i] = d.ell_w_idx[i];
+        s_wv[i] = d.ell_w_w[i];
+    }
+    const int he0 = d.inv_h_ptr[i0], he1 = d.inv_h_ptr[i1];
+    for (int i = threadIdx.x; i <= i1 - i0; i += RT) s_hp[i] = d.inv_h_ptr[i0 + i] - he0;
+    for (int i = threadIdx.x; i < he1 - he0; i += RT) {
+        s_hi[i] = d.inv_h_idx[he0 + i] - lo;
+        s_hv[i] = d.inv_h_w[he0 + i];
+    }
     __syncthreads();
-    const int i0 = blk * d.ti, i1 = min(d.in_h, i0 + d.ti);
     // H adjoint: T[i][o] = sum_{e in inv_h[i]} w_e * u[p_e][o]
     for (int it = threadIdx.x; it < (i1 - i0) * d.out_w; it += RT) {
         const int ii = it / d.out_w, o = it - ii * d.out_w;
-        const int e0 = d.inv_h_ptr[i0 + ii], e1 = d.inv_h_ptr[i0 + ii + 1];
+        const int e0 = s_hp[ii], e1 = s_hp[ii + 1];
         float acc = 0.0f;
-        for (int e = e0; e < e1; ++e) acc = fmaf(d.inv_h_w[e], s_u[(d.inv_h_idx[e] - lo) * d.out_w + o], acc);
+        for (int e = e0; e < e1; ++e) acc = fmaf(s_hv[e], s_u[s_hi[e] * d.out_w + o], acc);
         s_t[ii * d.out_w + o] = acc;
     }
     __syncthreads();
@@ -217,9 +258,9 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
         float g[U];
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            const int e0 = d.inv_w_ptr[j0 + q], e1 = d.inv_w_ptr[j0 + q + 1];
             float acc = 0.0f;
-            for (int e = e0; e < e1; ++e) acc = fmaf(d.inv_w_w[e], s_t[ii * d.out_w + d.inv_w_idx[e]], acc);
+            for (int k = 0; k < d.ell_w; ++k)
+                acc = fmaf(s_wv[k * d.in_w + j0 + q], s_t[ii * d.out_w + s_wi[k * d.in_w + j0 + q]], acc);
             g[q] = acc;
         }
         const int64_t o = (int64_t)(i0 + ii) * d.in_w + j0;
@@ -313,6 +354,21 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
     UP(hp, inv_h_ptr) UP(hi, inv_h_idx) UP(hw, inv_h_w)
     build_inverse(w_w, i_w, op->taps_w, op->out_w, op->in_w, ptr, oi, ow);
     UP(ptr, inv_w_ptr) UP(oi, inv_w_idx) UP(ow, inv_w_w)
+    d.nnz_w = (int)ow.size();
+    {   // ELL copy of the W inverse: same entry order per column (deterministic), zero padded
+        int ell = 1;
+        for (int j = 0; j < d.in_w; ++j) ell = std::max(ell, ptr[(size_t)j + 1] - ptr[(size_t)j]);
+        std::vector<int> ei((size_t)ell * d.in_w, 0);
+        std::vector<float> ew((size_t)ell * d.in_w, 0.0f);
+        for (int j = 0; j < d.in_w; ++j)
+            for (int e = ptr[(size_t)j]; e < ptr[(size_t)j + 1]; ++e) {
+                const int k = e - ptr[(size_t)j];
+                ei[(size_t)k * d.in_w + j] = oi[(size_t)e];
+                ew[(size_t)k * d.in_w + j] = ow[(size_t)e];
+            }
+        d.ell_w = ell;
+        UP(ei, ell_w_idx) UP(ew, ell_w_w)
+    }
 
     // ---- forward blocking: largest tp (<= 16) whose staged rows fit the LDS budget
     int best_tp = 0;
@@ -334,7 +390,7 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
             cnt[(size_t)b] = mx - mn + 1;
             maxrows = std::max(maxrows, mx - mn + 1);
         }
-        const size_t lds = ((size_t)maxrows * (d.in_w + d.out_w) + 16) * 4;
+        const size_t lds = ((size_t)maxrows * (d.in_w + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * tp)) * 4;
         if (lds <= kLdsBudget || tp == 1) {
             best_tp = tp; d.fwd_rows = maxrows; blo = lo; bcnt = cnt; own = ow_;
             if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
@@ -362,9 +418,12 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
             cnt[(size_t)b] = mx - mn + 1;
             maxrows = std::max(maxrows, mx - mn + 1);
         }
-        const size_t lds = ((size_t)(maxrows + ti) * d.out_w) * 4;
+        int max_he = 1;
+        for (int b = 0; b < nblk; ++b)
+            max_he = std::max(max_he, hp[(size_t)std::min(d.in_h, (b + 1) * ti)] - hp[(size_t)(b * ti)]);
+        const size_t lds = ((size_t)(maxrows + ti) * d.out_w + 2 * (size_t)(d.ell_w * d.in_w + max_he) + ti + 8) * 4;
         if (lds <= kLdsBudget || ti == 1) {
-            best_ti = ti; d.adj_rows = maxrows; alo = lo; acnt = cnt;
+            best_ti = ti; d.adj_rows = maxrows; alo = lo; acnt = cnt; d.max_he = max_he;
             if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
             break;
         }
@@ -418,7 +477,7 @@ static int launch_fwd(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
 {
     const ResizeDev &d = dev_of(op);
     const unsigned grid = (unsigned)(a.planes * ((d.out_h + d.tp - 1) / d.tp));
-    const size_t lds = ((size_t)d.fwd_rows * (d.in_w + d.out_w) + 16) * 4;
+    const size_t lds = ((size_t)d.fwd_rows * (d.in_w + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * d.tp)) * 4;
     if (vec) RZ_LAUNCH((k_resize_fwd<POST, RESID, true>), grid, lds, s, a, d);
     RZ_LAUNCH((k_resize_fwd<POST, RESID, false>), grid, lds, s, a, d);
 }
@@ -428,7 +487,7 @@ static int launch_adj(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
 {
     const ResizeDev &d = dev_of(op);
     const unsigned grid = (unsigned)(a.planes * ((d.in_h + d.ti - 1) / d.ti));
-    const size_t lds = ((size_t)(d.adj_rows + d.ti) * d.out_w) * 4;
+    const size_t lds = ((size_t)(d.adj_rows + d.ti) * d.out_w + 2 * (size_t)(d.ell_w * d.in_w + d.max_he) + d.ti + 8) * 4;
     if (vec) RZ_LAUNCH((k_resize_adj<EPI, true>), grid, lds, s, a, d);
     RZ_LAUNCH((k_resize_adj<EPI, false>), grid, lds, s, a, d);
 }

@@ -23,6 +23,8 @@ __device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
     return cnt;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int RR>
 struct SepGeom {
     static constexpr int RH = TH + 2 * RR;
@@ -200,16 +202,26 @@ __device__ __forceinline__ void hpass_inplace(float *s, const float (&taps)[2 * 
             const float4 v = *reinterpret_cast<const float4 *>(row + 4 * j);
             win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
         }
+        // two adjacent outputs per v_pk_fma_f32: (acc[o], acc[o+1]) += (tap[k-o], tap[k-o-1]) * (win[k], win[k])
+        v2f acc2[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc2[p] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < WN; ++k) {
+            const v2f b = v2f{win[k], win[k]};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int d0 = k - 2 * p, d1 = d0 - 1;
+                const bool ok0 = d0 >= 0 && d0 <= 2 * RR, ok1 = d1 >= 0 && d1 <= 2 * RR;
+                if (ok0 || ok1) {
+                    const v2f t = v2f{ok0 ? taps[ok0 ? d0 : 0] : 0.0f, ok1 ? taps[ok1 ? d1 : 0] : 0.0f};
+                    acc2[p] = __builtin_elementwise_fma(t, b, acc2[p]);
+                }
+            }
+        }
         float acc[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < WN; ++k)
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const int d = k - o;
-                if (d >= 0 && d <= 2 * RR) acc[o] = fmaf(taps[d], win[k], acc[o]);
-            }
+        for (int p = 0; p < 4; ++p) { acc[2 * p] = acc2[p].x; acc[2 * p + 1] = acc2[p].y; }
         if constexpr (FOLD == 1) {
             // pixel column j = 8 GG + o at distance j from the left edge: += sum_m f[RR+j+m] * U[m],
             // U[m] = region column RR + m = window element RR + m - 8 GG
@@ -262,23 +274,26 @@ __device__ __forceinline__ void vpass_regs(const float *s, float (&acc)[4][4], c
                                            const float (&taps)[2 * kMaxRadius + 1])
 {
     using G = SepGeom<RR>;
+    v2f a2[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
+    for (int i = 0; i < 4; ++i) a2[i][0] = a2[i][1] = v2f{0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 4 + 2 * RR; ++j) {
         const float4 v4 = *reinterpret_cast<const float4 *>(s + (4 * rg + j) * G::SW + 4 * cg);
+        const v2f lo = v2f{v4.x, v4.y}, hi = v2f{v4.z, v4.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int d = j - i;
             if (d >= 0 && d <= 2 * RR) {
-                acc[i][0] = fmaf(taps[d], v4.x, acc[i][0]);
-                acc[i][1] = fmaf(taps[d], v4.y, acc[i][1]);
-                acc[i][2] = fmaf(taps[d], v4.z, acc[i][2]);
-                acc[i][3] = fmaf(taps[d], v4.w, acc[i][3]);
+                const v2f t = v2f{taps[d], taps[d]};
+                a2[i][0] = __builtin_elementwise_fma(t, lo, a2[i][0]);      // v_pk_fma_f32
+                a2[i][1] = __builtin_elementwise_fma(t, hi, a2[i][1]);
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i][0] = a2[i][0].x; acc[i][1] = a2[i][0].y; acc[i][2] = a2[i][1].x; acc[i][3] = a2[i][1].y;
     }
     if constexpr (FOLD == 1) {
         // output row oy = 4 RG + i at distance oy from the top: += sum_m f[RR+oy+m] * T[m], T[m] = region row RR+m

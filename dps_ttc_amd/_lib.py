@@ -58,7 +58,7 @@ SIGNATURES = {
     "dpsx_step_resid_bytes": (_i64, [c_void_p, _i64, _i64, _i64, _i64]),
     "dpsx_step_fwd_f32": (c_int, [c_void_p, _f, _f, _f, _f, _i64, _f, _f, _p, _p, _f,
                                   _i64, _i64, _i64, _i64, POINTER(Coefs), _p, _i64, _p]),
-    "dpsx_step_bwd_f32": (c_int, [c_void_p, _p, _f, _p, _f, _f, _i64, c_float, c_int, _f,
+    "dpsx_step_bwd_f32": (c_int, [c_void_p, _p, _f, _f, _p, _f, _f, _i64, c_float, c_int, _f,
                                   _i64, _i64, _i64, _i64, POINTER(Coefs), _p, _i64, _p]),
     "dpsx_step_update_f32": (c_int, [_f, _f, _f, _f, _i64, _i64, POINTER(Coefs), _p]),
     "dpsx_update_f32": (c_int, [_f, _f, _f, _f, _i64, _p]),

@@ -404,8 +404,7 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
 {
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
-    if (!x_t || !model_out || !y || !x0_hat || !sample || !inside || !resid || !norm || !coefs_host)
-        return DPSX_EINVAL;
+    if (!x_t || !model_out || !y || !x0_hat || !sample || !inside || !resid || !coefs_host) return DPSX_EINVAL;
     if (coefs_host->add_noise && !noise) return DPSX_EINVAL;
     if (y_n != 1 && y_n != n) return DPSX_EINVAL;
     if (n == 0) return DPSX_OK;
@@ -442,25 +441,35 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
     default: return DPSX_EUNSUPPORTED;
     }
     if (rc != DPSX_OK) return rc;
-    return finalize_norm(ws.partials, parts, norm, n, s);
+    // norm == NULL: the partial sums stay in `workspace` and dpsx_step_bwd_f32 finalises them in its prologue
+    return norm ? finalize_norm(ws.partials, parts, norm, n, s) : DPSX_OK;
 }
 
-int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, const uint8_t *inside,
+int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *norm_out, const uint8_t *inside,
                       const float *x0_hat, const float *y, int64_t y_n, float scale, int power,
                       float *g_model_out, int64_t n, int64_t c, int64_t h, int64_t w,
                       const dpsx_coefs *coefs_host, void *workspace, int64_t workspace_bytes, void *stream)
 {
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
-    if (!resid || !norm || !inside || !g_model_out || !coefs_host || (power != 1 && power != 2)) return DPSX_EINVAL;
+    if (!resid || !inside || !g_model_out || !coefs_host || (power != 1 && power != 2)) return DPSX_EINVAL;
+    if (!norm && !norm_out) return DPSX_EINVAL;
     if (n == 0) return DPSX_OK;
     Ws ws;
     if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const Coefs k = to_coefs(coefs_host);
     const int64_t chw = c * h * w;
-    StepBwdArgs b{static_cast<const float *>(resid), norm, inside, x0_hat, y, y_n, scale, power, g_model_out,
-                  n, c, h, w, k};
+    int parts = (int)parts_per_particle(op, c, h, w);
+    if (op->kind == OP_IDENT || op->kind == OP_PHASE) {
+        if (op->kind == OP_IDENT) parts = 64;
+        if (!norm) {                      // these two have no fused prologue: finalise with the small kernel
+            if ((rc = finalize_norm(ws.partials, parts, norm_out, n, s)) != DPSX_OK) return rc;
+            norm = norm_out;
+        }
+    }
+    StepBwdArgs b{static_cast<const float *>(resid), norm, ws.partials, parts, norm_out, inside, x0_hat, y, y_n,
+                  scale, power, g_model_out, n, c, h, w, k};
     switch (op->kind) {
     case OP_SEP:
     case OP_TAPS: return blur_step_bwd(op, b, s);

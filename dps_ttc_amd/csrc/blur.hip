@@ -37,7 +37,10 @@ struct BlurArgs {
     int y_n;
     float *partials;      // [planes * tiles]
     // adjoint epilogue (EPI)
-    const float *norm_in; // [n] (finalized by the forward half of the step)
+    const float *norm_in; // [n] finalized norms, or nullptr: derive from norm_partials (fused bwd half)
+    const float *norm_partials;
+    int norm_parts;
+    float *norm_out;
     const uint8_t *inside_r;
     float *g_model_out;
     float scale;
@@ -299,9 +302,16 @@ __global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int ra
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
     float coef = 0.0f;
-    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
+    float *s_nrm = lds + RH * SW;
+    if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm); }
     load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
     __syncthreads();
+    if constexpr (EPI) {
+        const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_nrm[0];
+        coef = norm_coef_dev(nv, a.scale, a.power);
+        if (!a.norm_in && a.norm_out && threadIdx.x == 0 && ty == 0 && tx == 0 && plane % a.c == 0)
+            a.norm_out[plane / a.c] = nv;
+    }
     const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
     float acc[GI];
 #pragma unroll
@@ -533,7 +543,7 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
     if (b.n == 0) return DPSX_OK;
     BlurArgs a{};
     a.x = b.resid;
-    a.norm_in = b.norm;
+    a.norm_in = b.norm; a.norm_partials = b.partials; a.norm_parts = b.parts; a.norm_out = b.norm_out;
     a.inside_r = b.inside; a.g_model_out = b.g_model_out; a.scale = b.scale; a.power = b.power;
     a.k = b.k;
     fill_geometry(a, b.n * b.c, b.c, b.h, b.w);

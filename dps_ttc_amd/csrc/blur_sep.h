@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
     float coef = 0.0f;
-    if constexpr (EPI) coef = norm_coef_dev(a.norm_in[plane / a.c], a.scale, a.power);
+    if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_th + 160); }
     // ---- which folds does this tile need (all block-uniform)
     const bool lfold = reach > 0 && w0 == 0, rfold = reach > 0 && w0 + TW >= a.w - 1 - reach;
     const bool tfold = reach > 0 && h0 == 0, bfold = reach > 0 && h0 + TH >= a.h - 1 - reach;
@@ -418,6 +418,12 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
         }
     if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
     __syncthreads();
+    if constexpr (EPI) {
+        const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_th[160];
+        coef = norm_coef_dev(nv, a.scale, a.power);
+        if (!a.norm_in && a.norm_out && threadIdx.x == 0 && ty == 0 && tx == 0 && plane % a.c == 0)
+            a.norm_out[plane / a.c] = nv;
+    }
     // ---- horizontal fold terms from the untouched cotangent, kept in registers across the in-place pass
     float fold[G::FOLD_PER_THREAD];
     int fold_col[G::FOLD_PER_THREAD];

@@ -94,6 +94,21 @@ __device__ __forceinline__ float block_sum(float v, float *scratch)
     return t;
 }
 
+// Per-particle norm from the per-block partial sums of squares the forward half left behind.  Same
+// order as k_finalize_norm (lane-strided sums, fixed shuffle tree, double), so every block of a particle
+// -- and the stand-alone finalisation -- get the bit-identical value.  Called by all threads; the result is
+// valid in *slot after the next __syncthreads().
+__device__ __forceinline__ void particle_norm_to_lds(const float *partials, int parts, int64_t n, float *slot)
+{
+    if (threadIdx.x < kWave) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < parts; i += kWave) acc += (double)partials[n * parts + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+        if (threadIdx.x == 0) *slot = (float)sqrt(acc);
+    }
+}
+
 // ReflectionPad2d index map (no edge repeat); valid while |overhang| < n.
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
@@ -148,7 +163,10 @@ struct StepFwdArgs {
 };
 
 struct StepBwdArgs {
-    const float *resid, *norm;
+    const float *resid, *norm;   // norm == nullptr: derive it from `partials` (parts per particle) and write norm_out
+    const float *partials;
+    int parts;
+    float *norm_out;
     const uint8_t *inside;
     const float *x0_hat, *y;
     int64_t y_n;

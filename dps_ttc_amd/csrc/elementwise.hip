@@ -334,11 +334,17 @@ int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &a, int parts, hipStream_
 __global__ __launch_bounds__(kThreads) void k_mask_step_bwd(StepBwdArgs a, const float *__restrict__ mask,
                                                             int64_t chw, int64_t hw)
 {
+    __shared__ float s_nrm[1];
     const int64_t p = blockIdx.y;
     const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (!a.norm) {                                   // block-uniform: derive the norm from the forward half's partials
+        particle_norm_to_lds(a.partials, a.parts, p, s_nrm);
+        __syncthreads();
+        if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[p] = s_nrm[0];
+    }
     if (i >= chw) return;
     const int64_t o = p * chw + i;
-    const float coef = norm_coef(a.norm[p], a.scale, a.power);  // cotangent on A x0 is coef * r
+    const float coef = norm_coef(a.norm ? a.norm[p] : s_nrm[0], a.scale, a.power);  // cotangent on A x0 is coef * r
     const float4 x0 = *reinterpret_cast<const float4 *>(a.x0_hat + o);
     const float4 mv = *reinterpret_cast<const float4 *>(mask + (i % hw));
     const float4 yv = *reinterpret_cast<const float4 *>(a.y + (a.y_n == 1 ? 0 : p) * chw + i);

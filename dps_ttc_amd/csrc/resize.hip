@@ -54,7 +54,9 @@ struct ResizeArgs {
     const float *y;
     int y_n;
     float *partials;
-    const float *norm_in;
+    const float *norm_in, *norm_partials;
+    int norm_parts;
+    float *norm_out;
     const uint8_t *inside_r;
     float *g_model_out;
     float scale;
@@ -237,6 +239,8 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
         s_hi[i] = d.inv_h_idx[he0 + i] - lo;
         s_hv[i] = d.inv_h_w[he0 + i];
     }
+    float *s_nrm = reinterpret_cast<float *>(s_hi + d.max_he);
+    if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm); }
     __syncthreads();
     // H adjoint: T[i][o] = sum_{e in inv_h[i]} w_e * u[p_e][o]
     for (int it = threadIdx.x; it < (i1 - i0) * d.out_w; it += RT) {
@@ -249,7 +253,11 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     __syncthreads();
     float coef = 0.0f;
     const int n = plane / a.c, ch = plane % a.c;
-    if constexpr (EPI) coef = norm_coef_r(a.norm_in[n], a.scale, a.power);
+    if constexpr (EPI) {
+        const float nv = a.norm_in ? a.norm_in[n] : s_nrm[0];
+        coef = norm_coef_r(nv, a.scale, a.power);
+        if (!a.norm_in && a.norm_out && threadIdx.x == 0 && blk == 0 && ch == 0) a.norm_out[n] = nv;
+    }
     // W adjoint: g[i][j] = sum_{e in inv_w[j]} w_e * T[i][o_e]
     constexpr int U = VEC ? 4 : 1;
     const int wu = d.in_w / U;
@@ -532,7 +540,8 @@ int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
 {
     if (b.n == 0) return DPSX_OK;
     ResizeArgs a{};
-    a.x = b.resid; a.norm_in = b.norm; a.inside_r = b.inside; a.g_model_out = b.g_model_out;
+    a.x = b.resid; a.norm_in = b.norm; a.norm_partials = b.partials; a.norm_parts = b.parts; a.norm_out = b.norm_out;
+    a.inside_r = b.inside; a.g_model_out = b.g_model_out;
     a.scale = b.scale; a.power = b.power; a.c = (int)b.c; a.planes = (int)(b.n * b.c); a.k = b.k;
     const bool vec = rz_vec(op, {b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
     return launch_adj<true>(op, a, vec, s);

@@ -313,11 +313,15 @@ class StepBuffers:
         self.flip = 0
 
 
-def step_fwd(handle, buf, x_t, model_out, noise, y, coefs):
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False):
+    """K1.  With finalize_norm=False (the loop's setting) buf.norm is filled by the following step_bwd, whose
+    prologue finalises the per-tile partial sums this launch leaves in the workspace (one launch fewer)."""
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, x_t.device)
+    buf.norm_ready = bool(finalize_norm)
     check(lib().dpsx_step_fwd_f32(handle._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0],
-                                  ptr(buf.x0_hat), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid), ptr(buf.norm),
+                                  ptr(buf.x0_hat), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid),
+                                  ptr(buf.norm) if finalize_norm else None,
                                   n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(x_t)),
           "dpsx_step_fwd_f32")
 
@@ -325,10 +329,13 @@ def step_fwd(handle, buf, x_t, model_out, noise, y, coefs):
 def step_bwd(handle, buf, y, scale, power, coefs):
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, buf.x0_hat.device)
-    check(lib().dpsx_step_bwd_f32(handle._h, ptr(buf.resid), ptr(buf.norm), ptr(buf.inside), ptr(buf.x0_hat),
+    ready = getattr(buf, "norm_ready", True)
+    check(lib().dpsx_step_bwd_f32(handle._h, ptr(buf.resid), ptr(buf.norm) if ready else None, ptr(buf.norm),
+                                  ptr(buf.inside), ptr(buf.x0_hat),
                                   ptr(y), y.shape[0], float(scale), int(power), ptr(buf.g_model_out),
                                   n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(buf.x0_hat)),
           "dpsx_step_bwd_f32")
+    buf.norm_ready = True
 
 
 def step_update(buf, g_unet, coefs):

@@ -139,13 +139,17 @@ int dpsx_norm_bwd_f32(const float *r, const float *norm, const float *g_norm, in
  * the residual (or, for phase retrieval, the complex cotangent) from fwd to bwd. */
 int64_t dpsx_step_resid_bytes(const dpsx_op *op, int64_t n, int64_t c, int64_t h, int64_t w);
 
+/* norm may be NULL: the per-particle norms are then finalised by dpsx_step_bwd_f32 (see there). */
 int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise,
                       const float *y, int64_t y_n,
                       float *x0_hat, float *sample, uint8_t *inside, void *resid, float *norm,
                       int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
                       void *workspace, int64_t workspace_bytes, void *stream);
 
-int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, const uint8_t *inside,
+/* norm: the norms dpsx_step_fwd_f32 produced, or NULL when that call was given norm == NULL: the partial sums
+ * it left in `workspace` (same buffer, untouched in between) are then finalised in this launch's prologue --
+ * saving a launch per step -- and written to norm_out (required in that case, optional otherwise). */
+int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *norm_out, const uint8_t *inside,
                       const float *x0_hat, const float *y, int64_t y_n,
                       float scale, int power, float *g_model_out,
                       int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,

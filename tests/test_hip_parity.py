@@ -245,7 +245,7 @@ def test_residual_norm_and_vjp(K, oracle):
 
 
 # ----------------------------------------------------------------- fused DPS step vs oracle
-def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None):
+def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False):
     rng = np.random.RandomState(seed)
     sched = oracle.tables.schedule(1000)
     c, ck = coefs_of(K, oracle, t, sched)
@@ -263,7 +263,9 @@ def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask
     ref = oracle.dps_step(orc, x_prev, mo, noise, y, c, scale=scale, power=power, g_unet_fn=lambda g: g_unet)
     handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(dev(x_prev))
     buf = K.StepBuffers(handle, n, 3, hw, hw, DEV)
-    K.step_fwd(handle, buf, dev(x_prev), dev(mo), dev(noise), dev(y), ck)
+    K.step_fwd(handle, buf, dev(x_prev), dev(mo), dev(noise), dev(y), ck, finalize_norm=finalize)
+    if finalize:        # norms already final after K1 (the stand-alone finalisation kernel)
+        assert rel_l2(host(buf.norm), ref["norm"]) < TOL
     K.step_bwd(handle, buf, dev(y), scale, power, ck)
     x_next = K.step_update(buf, dev(g_unet), ck)
     np.testing.assert_array_equal(host(buf.x0_hat), ref["x0_hat"])
@@ -292,6 +294,10 @@ def test_fused_step_vs_oracle(K, oracle, golden, name, hw, t, power):
 def test_fused_step_full_size_headline(K, oracle):
     """BASELINE headline geometry (Gaussian deblur, 256 x 256) on a particle subset the oracle finishes fast."""
     _fused_case(K, oracle, "gauss", 2, 256, 500, 0.3, 1, seed=11)
+    _fused_case(K, oracle, "gauss", 2, 256, 500, 0.3, 2, seed=12, finalize=True)
+    for name in ("sr4", "inpaint", "motion", "phase"):
+        _fused_case(K, oracle, name, 2, 64 if name != "phase" else 32, 300, 0.5, 1, seed=13, finalize=True,
+                    kernel=synthetic_motion_kernel(61, 4), mask=(np.random.RandomState(3).rand(1, 1, 64, 64) < 0.5).astype(np.float32))
 
 
 # ----------------------------------------------------------------- conditioning per call (registry API, autograd path)

@@ -90,11 +90,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     import torch.distributed as dist
+    local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DPSX_BENCH_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" only to rehearse on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from dps_ttc_amd import distributed as dd
     from dps_ttc_amd import kernels

@@ -256,6 +256,7 @@ int64_t dpsx_op_workspace_bytes(const dpsx_op *op, int64_t n, int64_t c, int64_t
     if (m < 0) return DPSX_EINVAL;
     int64_t parts = std::max<int64_t>(parts_per_particle(op, c, h, w), 64);
     int64_t bytes = align256(n * parts * 4);
+    if (op->kind == OP_SEP || op->kind == OP_TAPS) bytes += blur_adjoint_scratch_bytes(op, n * c, h, w);
     if (op->kind == OP_PHASE || op->kind == OP_IDENT || op->kind == OP_MASK) {
         bytes += align256(n * m * 4) + align256(n * c * h * w * 4);
         if (op->kind == OP_PHASE) bytes += phase_workspace_bytes(op, n * c);
@@ -283,6 +284,10 @@ static int carve(const dpsx_op *op, void *ws, int64_t ws_bytes, int64_t n, int64
     o.meas = o.img = nullptr;
     o.priv = nullptr;
     o.priv_bytes = 0;
+    if (op->kind == OP_SEP || op->kind == OP_TAPS) {
+        o.priv = p;
+        o.priv_bytes = blur_adjoint_scratch_bytes(op, n * c, h, w);
+    }
     if (op->kind == OP_PHASE || op->kind == OP_IDENT || op->kind == OP_MASK) {
         const int64_t m = meas_elems(op, c, h, w);
         o.meas = reinterpret_cast<float *>(p);
@@ -336,7 +341,11 @@ int dpsx_op_adjoint_f32(dpsx_op *op, const float *u, const float *x, float *g, i
     hipStream_t s = (hipStream_t)stream;
     switch (op->kind) {
     case OP_SEP:
-    case OP_TAPS: return blur_adjoint(op, u, g, n * c, h, w, s);
+    case OP_TAPS: {
+        Ws ws;
+        if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
+        return blur_adjoint(op, u, g, n * c, h, w, static_cast<float *>(ws.priv), ws.priv_bytes, s);
+    }
     case OP_RESIZE: return resize_adjoint(op, u, g, n * c, s);
     case OP_MASK: return mask_mul(u, op->mask, g, n * c, h * w, s);
     case OP_IDENT:
@@ -472,7 +481,7 @@ int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *
                   scale, power, g_model_out, n, c, h, w, k};
     switch (op->kind) {
     case OP_SEP:
-    case OP_TAPS: return blur_step_bwd(op, b, s);
+    case OP_TAPS: return blur_step_bwd(op, b, static_cast<float *>(ws.priv), ws.priv_bytes, s);
     case OP_RESIZE: return resize_step_bwd(op, b, s);
     case OP_MASK:
         if (!x0_hat || !y || (y_n != 1 && y_n != n)) return DPSX_EINVAL;

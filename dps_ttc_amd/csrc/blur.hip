@@ -53,6 +53,9 @@ struct BlurArgs {
     const float *tap_w;
     int nnz;
     int dbg;   // diagnostic phase mask (env DPSX_DBG), 0 in production
+    // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
+    // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
+    int src_h, src_w, src_off;
 };
 
 __device__ __forceinline__ bool block_to_tile(const BlurArgs &a, int &plane, int &ty, int &tx)
@@ -77,7 +80,7 @@ __device__ __forceinline__ void load_region(float *s_in, const int SW, const int
                                             const int gy0, const int gx0, const int h0, const int w0,
                                             const BlurArgs &a, const int plane)
 {
-    const int h = a.h, w = a.w;
+    const int h = REFLECT ? a.h : a.src_h, w = REFLECT ? a.w : a.src_w, off = REFLECT ? 0 : a.src_off;
     const int64_t hw = (int64_t)h * w;
     const int n = plane / a.c, ch = plane % a.c;
     const float *src = nullptr, *eps = nullptr, *vv = nullptr, *zz = nullptr;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void load_region(float *s_in, const int SW, const int
     const int RWu = RW / U;
     for (int u = threadIdx.x; u < RH * RWu; u += NT) {
         const int rr = u / RWu, cu = u - rr * RWu;
-        const int gy = gy0 + rr, gx = gx0 + cu * U;
+        const int gy = gy0 + rr - off, gx = gx0 + cu * U - off;     // coordinates in the source plane
         float val[U];
         float ev[U];
         bool rowok = true;
@@ -291,9 +294,14 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
     }
 }
 
-// adjoint: g[i][j] = sum_{p in {i} U fold(i)} sum_{q in {j} U fold(j)} sum_taps w * u_z[p - dy][q - dx]
-template <bool EPI, bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int radius)
+// Adjoint of the tap-list operator in two launches (deterministic, no atomics):
+//   k_blur_taps_corrT : V = C^T u on the whole PADDED domain (h + 2 R4) x (w + 2 R4): the correlation-transpose
+//                       of the zero-extended cotangent, V[p][q] = sum_t w_t * u_z[p - dy_t][q - dx_t].  Uniform
+//                       work for every tile -- no border special cases in the tap loop.
+//   k_blur_fold       : reflection_pad2d backward, g[i][j] = sum over the <= 3 x 3 padded positions that
+//                       ReflectionPad maps onto (i, j), fused with the clamp gate / -b*coef epilogue of the step.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, int RR)
 {
     const int RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
     extern __shared__ __align__(16) float lds[];
@@ -301,22 +309,12 @@ __global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int ra
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    float coef = 0.0f;
-    float *s_nrm = lds + RH * SW;
-    if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm); }
     load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
     __syncthreads();
-    if constexpr (EPI) {
-        const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_nrm[0];
-        coef = norm_coef_dev(nv, a.scale, a.power);
-        if (!a.norm_in && a.norm_out && threadIdx.x == 0 && ty == 0 && tx == 0 && plane % a.c == 0)
-            a.norm_out[plane / a.c] = nv;
-    }
     const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
     float acc[GI];
 #pragma unroll
     for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
-    // main term (p = i, q = j): always inside the region
     const float *base = s_in + (r0 + RR) * SW + col + RR;
     for (int t = 0; t < a.nnz; ++t) {
         const float wgt = a.tap_w[t];
@@ -324,38 +322,55 @@ __global__ __launch_bounds__(NT) void k_blur_taps_adj(BlurArgs a, int RR, int ra
 #pragma unroll
         for (int i = 0; i < GI; ++i) acc[i] = fmaf(wgt, p[4 * i * SW], acc[i]);
     }
-    const bool border = (w0 <= radius) || (w0 + TW >= a.w - 1 - radius) || (h0 <= radius) ||
-                        (h0 + TH >= a.h - 1 - radius);
     const int ox = w0 + col;
-    if (border && ox < a.w) {
-        int sx[2];
-        const int nx = fold_sources(ox, a.w, radius, sx);
-        const int qs[3] = {ox, sx[0], sx[1]};
-        for (int i = 0; i < GI; ++i) {
-            const int oy = h0 + r0 + 4 * i;
-            if (oy >= a.h) continue;
-            int sy[2];
-            const int ny = fold_sources(oy, a.h, radius, sy);
-            if (nx == 0 && ny == 0) continue;
-            const int ps[3] = {oy, sy[0], sy[1]};
-            float add = 0.0f;
-            for (int ip = 0; ip <= ny; ++ip)
-                for (int iq = 0; iq <= nx; ++iq) {
-                    if (ip == 0 && iq == 0) continue;  // main term done
-                    const int pr = ps[ip] - (h0 - RR), qc = qs[iq] - (w0 - RR);
-                    for (int t = 0; t < a.nnz; ++t) {
-                        const int row = pr - a.tap_dy[t], cc = qc - a.tap_dx[t];
-                        if (row >= 0 && row < RH && cc >= 0 && cc < RW)
-                            add = fmaf(a.tap_w[t], s_in[row * SW + cc], add);
-                    }
-                }
-            acc[i] += add;
-        }
-    }
     if (ox < a.w) {
 #pragma unroll
-        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + 4 * i, ox, &acc[i], coef, EPI, 1);
+        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + 4 * i, ox, &acc[i], 0.0f, false, 1);
     }
+}
+
+struct FoldArgs {
+    const float *v;       // [planes, ph, pw] padded-domain correlation-transpose
+    float *g;             // !EPI: [planes, h, w]
+    const float *norm_in, *norm_partials;
+    int norm_parts;
+    float *norm_out;
+    const uint8_t *inside;
+    float *g_model_out;
+    float scale, neg_b;
+    int power, c, h, w, ph, pw, off, reach;
+};
+
+template <bool EPI>
+__global__ __launch_bounds__(NT) void k_blur_fold(FoldArgs f)
+{
+    __shared__ float s_nrm[1];
+    const int plane = blockIdx.y, n = plane / f.c, ch = plane % f.c;
+    float coef = 0.0f;
+    if constexpr (EPI) {
+        if (!f.norm_in) {
+            particle_norm_to_lds(f.norm_partials, f.norm_parts, n, s_nrm);
+            __syncthreads();
+        }
+        const float nv = f.norm_in ? f.norm_in[n] : s_nrm[0];
+        coef = norm_coef_dev(nv, f.scale, f.power);
+        if (!f.norm_in && f.norm_out && blockIdx.x == 0 && threadIdx.x == 0 && ch == 0) f.norm_out[n] = nv;
+    }
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= f.h * f.w) return;
+    const int i = idx / f.w, j = idx - i * f.w;
+    int sy[2], sx[2];
+    const int ny = fold_sources(i, f.h, f.reach, sy), nx = fold_sources(j, f.w, f.reach, sx);
+    const int ps[3] = {i, sy[0], sy[1]}, qs[3] = {j, sx[0], sx[1]};
+    const float *vp = f.v + (int64_t)plane * f.ph * f.pw;
+    float acc = 0.0f;
+    for (int a = 0; a <= ny; ++a)
+        for (int b = 0; b <= nx; ++b) acc += vp[(int64_t)(ps[a] + f.off) * f.pw + (qs[b] + f.off)];
+    const int64_t o = (int64_t)i * f.w + j, hw = (int64_t)f.h * f.w;
+    if constexpr (EPI)
+        f.g_model_out[((int64_t)n * 2 * f.c + ch) * hw + o] = f.inside[(int64_t)plane * hw + o] ? f.neg_b * (coef * acc) : 0.0f;
+    else
+        f.g[(int64_t)plane * hw + o] = acc;
 }
 
 // =====================================================================
@@ -375,6 +390,7 @@ static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int
     a.tiles_y = (int)((h + TH - 1) / TH);
     static const int dbg = getenv("DPSX_DBG") ? atoi(getenv("DPSX_DBG")) : 0;
     a.dbg = dbg;
+    a.src_h = (int)h; a.src_w = (int)w; a.src_off = 0;
 }
 
 static inline unsigned grid_blocks(const BlurArgs &a)
@@ -476,13 +492,46 @@ static int launch_taps_fwd(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t 
     DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, false>), grid_blocks(a), lds, s, a, op->radius4);
 }
 
-template <bool EPI>
-static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t s)
+int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h, int64_t w)
 {
-    set_taps(op, a);
-    const size_t lds = taps_lds_bytes(op->radius4);
-    if (vec) DPSX_LAUNCH((k_blur_taps_adj<EPI, true>), grid_blocks(a), lds, s, a, op->radius4, op->reach);
-    DPSX_LAUNCH((k_blur_taps_adj<EPI, false>), grid_blocks(a), lds, s, a, op->radius4, op->reach);
+    // the padded-domain buffer of the two-launch adjoint; the separable 16-byte path does not need it
+    if (op->kind == OP_SEP && w % 4 == 0 && (h * w) % 4 == 0) return 0;
+    const int64_t r4 = op->radius4;
+    return ((planes * (h + 2 * r4) * (w + 2 * r4) * 4 + 255) / 256) * 256;
+}
+
+template <bool EPI>
+static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scratch, int64_t scratch_bytes,
+                           hipStream_t s)
+{
+    const int r4 = op->radius4;
+    const int ph = a.h + 2 * r4, pw = a.w + 2 * r4;
+    if (!scratch || scratch_bytes < (int64_t)a.planes * ph * pw * 4) return DPSX_EWORKSPACE;
+    // 1. V = C^T u on the padded domain
+    BlurArgs c{};
+    c.x = a.x; c.out = scratch;
+    fill_geometry(c, a.planes, 1, ph, pw);
+    c.src_h = a.h; c.src_w = a.w; c.src_off = r4;
+    set_taps(op, c);
+    const size_t lds = taps_lds_bytes(r4);
+    const bool v2 = vec && aligned16(scratch);
+    {
+        static bool done_v = false, done_s = false;
+        int rc = v2 ? allow_lds(&k_blur_taps_corrT<true>, lds, done_v) : allow_lds(&k_blur_taps_corrT<false>, lds, done_s);
+        if (rc != DPSX_OK) return rc;
+        if (v2) hipLaunchKernelGGL(k_blur_taps_corrT<true>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, r4);
+        else hipLaunchKernelGGL(k_blur_taps_corrT<false>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, r4);
+        if ((rc = check_launch()) != DPSX_OK) return rc;
+    }
+    // 2. fold + epilogue
+    FoldArgs f{};
+    f.v = scratch; f.g = a.out; f.norm_in = a.norm_in; f.norm_partials = a.norm_partials; f.norm_parts = a.norm_parts;
+    f.norm_out = a.norm_out; f.inside = a.inside_r; f.g_model_out = a.g_model_out; f.scale = a.scale;
+    f.neg_b = -a.k.b; f.power = a.power; f.c = a.c; f.h = a.h; f.w = a.w; f.ph = ph; f.pw = pw; f.off = r4;
+    f.reach = op->reach;
+    const dim3 grid((unsigned)((a.h * a.w + NT - 1) / NT), (unsigned)a.planes);
+    hipLaunchKernelGGL(k_blur_fold<EPI>, grid, dim3(NT), 0, s, f);
+    return check_launch();
 }
 
 static bool geometry_ok(const dpsx_op *op, int64_t h, int64_t w)
@@ -511,7 +560,8 @@ int blur_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, in
                                      : launch_taps_fwd<false, false>(op, a, vec, s);
 }
 
-int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, hipStream_t s)
+int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, float *scratch,
+                 int64_t scratch_bytes, hipStream_t s)
 {
     if (!geometry_ok(op, h, w)) return DPSX_EINVAL;
     if (planes == 0) return DPSX_OK;
@@ -519,7 +569,8 @@ int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, in
     a.x = u; a.out = g;
     fill_geometry(a, planes, 1, h, w);
     const bool vec = vec_ok(h, w, {u, g});
-    return op->kind == OP_SEP && vec ? dispatch_sep_adj<false>(op, a, s) : launch_taps_adj<false>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_adj<false>(op, a, s)
+                                     : launch_taps_adj<false>(op, a, vec, scratch, scratch_bytes, s);
 }
 
 int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
@@ -537,7 +588,7 @@ int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
     return op->kind == OP_SEP && vec ? dispatch_sep_fwd<true, true>(op, a, s) : launch_taps_fwd<true, true>(op, a, vec, s);
 }
 
-int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
+int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, float *scratch, int64_t scratch_bytes, hipStream_t s)
 {
     if (!geometry_ok(op, b.h, b.w)) return DPSX_EINVAL;
     if (b.n == 0) return DPSX_OK;
@@ -548,7 +599,8 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
     a.k = b.k;
     fill_geometry(a, b.n * b.c, b.c, b.h, b.w);
     const bool vec = vec_ok(b.h, b.w, {b.resid, b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
-    return op->kind == OP_SEP && vec ? dispatch_sep_adj<true>(op, a, s) : launch_taps_adj<true>(op, a, vec, s);
+    return op->kind == OP_SEP && vec ? dispatch_sep_adj<true>(op, a, s)
+                                     : launch_taps_adj<true>(op, a, vec, scratch, scratch_bytes, s);
 }
 
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,

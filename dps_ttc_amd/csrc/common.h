@@ -179,9 +179,11 @@ struct StepBwdArgs {
 
 // blur.hip
 int blur_forward(const dpsx_op *op, const float *x, float *y, int64_t planes, int64_t h, int64_t w, hipStream_t s);
-int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, hipStream_t s);
+int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, int64_t h, int64_t w, float *scratch,
+                 int64_t scratch_bytes, hipStream_t s);
+int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h, int64_t w);
 int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &a, hipStream_t s);
-int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
+int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &a, float *scratch, int64_t scratch_bytes, hipStream_t s);
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
                int64_t n, int64_t c, int64_t h, int64_t w, hipStream_t s);
 int64_t blur_parts_per_particle(const dpsx_op *op, int64_t c, int64_t h, int64_t w);

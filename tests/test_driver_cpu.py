@@ -1,0 +1,96 @@
+"""CPU suite: driver-side plumbing (YAML configs, dataset glob, mask generator, PSNR, UNet architecture)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shipped_yaml_configs_parse_and_build_host_objects():
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    from dps_ttc_amd.measurements import get_noise, get_operator
+    diff = yaml.load(open(os.path.join(ROOT, "configs", "diffusion_config.yaml")), Loader=yaml.FullLoader)
+    s = create_sampler(**diff)
+    assert s.num_timesteps == 1000 and s.hip_posterior
+    seen = set()
+    for f in sorted(glob.glob(os.path.join(ROOT, "configs", "*_config*.yaml"))):
+        cfg = yaml.load(open(f), Loader=yaml.FullLoader)
+        if "measurement" not in cfg:
+            continue
+        opcfg = cfg["measurement"]["operator"]
+        seen.add(opcfg["name"])
+        op = get_operator(device="cpu", **opcfg)                       # host tables only; no GPU needed
+        noiser = get_noise(**cfg["measurement"]["noise"])
+        params = dict(cfg["conditioning"]["params"])
+        if params.get("sem_guid_scale", 0) != 0:
+            params["embedder"] = lambda x: x.flatten(1)                 # the face network is pluggable
+        cm = get_conditioning_method(cfg["conditioning"]["method"], op, noiser, **params)
+        assert callable(cm.conditioning)
+        if opcfg["name"] == "super_resolution":
+            assert isinstance(opcfg["in_shape"], tuple)                 # !!python/tuple survives FullLoader
+    assert seen == {"gaussian_blur", "motion_blur", "super_resolution", "inpainting", "phase_retrieval"}
+
+
+def test_dataset_glob_and_transform(tmp_path):
+    from PIL import Image
+    from dps_ttc_amd.data import get_dataloader, get_dataset, to_minus1_1
+    rng = np.random.RandomState(0)
+    for name in ("b.png", "a.png", "sub/c.png"):
+        p = tmp_path / name
+        p.parent.mkdir(exist_ok=True)
+        Image.fromarray(rng.randint(0, 255, (16, 16, 4), dtype=np.uint8), "RGBA").save(p)
+    ds = get_dataset("ffhq", root=str(tmp_path), transforms=to_minus1_1)
+    assert [os.path.basename(p) for p in ds.fpaths] == ["a.png", "b.png", "c.png"] and len(ds) == 3
+    x = ds[0]
+    assert x.shape == (3, 16, 16) and x.dtype == torch.float32 and -1 <= float(x.min()) and float(x.max()) <= 1
+    batch = next(iter(get_dataloader(ds, batch_size=1, num_workers=0, train=False)))
+    assert batch.shape == (1, 3, 16, 16)
+    with pytest.raises(NameError):
+        get_dataset("no_such_dataset", root=".")
+    with pytest.raises(AssertionError):
+        get_dataset("ffhq", root=str(tmp_path / "empty"))
+
+
+def test_mask_generator_and_psnr():
+    from dps_ttc_amd.img_utils import clear_color, mask_generator
+    from dps_ttc_amd.metrics import compute_psnr, compute_psnr_manual
+    img = torch.zeros(1, 3, 64, 64)
+    np.random.seed(1)
+    m = mask_generator("random", mask_prob_range=(0.3, 0.7), image_size=64)(img)
+    assert m.shape == (1, 3, 64, 64) and set(m.unique().tolist()) == {0.0, 1.0}
+    assert torch.equal(m[:, 0], m[:, 1]) and 0.25 < 1 - float(m.mean()) < 0.75
+    np.random.seed(1)
+    b = mask_generator("box", mask_len_range=(16, 17), image_size=64, margin=(4, 4))(img)
+    assert float((b == 0).sum()) == 3 * 16 * 16
+    a = torch.rand(1, 3, 8, 8) * 2 - 1
+    assert float(compute_psnr(a, a + 0.01)) == pytest.approx(10 * np.log10(float((a.max() - a.min()) ** 2) / 1e-4), rel=1e-4)
+    assert float(compute_psnr_manual(a, a + 0.1)) == pytest.approx(20.0, rel=1e-4)
+    c = clear_color(a)
+    assert c.shape == (8, 8, 3) and c.min() == 0 and c.max() == pytest.approx(1.0)
+
+
+def test_unet_architecture_matches_the_checkpoint_layout():
+    """parameter count the survey probed on the reference: 93.6 M (FFHQ) -- and the key names load_state_dict needs"""
+    from dps_ttc_amd.unet import create_model
+    cfg = yaml.load(open(os.path.join(ROOT, "configs", "model_config.yaml")), Loader=yaml.FullLoader)
+    m = create_model(**cfg)                      # no checkpoint in the container -> random init, as the reference
+    n = sum(p.numel() for p in m.parameters())
+    assert n == 93_563_910
+    keys = set(m.state_dict())
+    for k in ("time_embed.0.weight", "input_blocks.0.0.weight", "input_blocks.1.0.in_layers.0.weight",
+              "input_blocks.1.0.emb_layers.1.weight", "input_blocks.1.0.out_layers.3.weight",
+              "middle_block.1.qkv.weight", "middle_block.1.proj_out.weight", "output_blocks.0.0.skip_connection.weight",
+              "out.2.weight"):
+        assert k in keys, k
+    x = torch.randn(2, 3, 64, 64, requires_grad=True)
+    y = m(x, torch.tensor([250.0]))              # t of shape [1] broadcasts over the particles, as in the loop
+    assert y.shape == (2, 6, 64, 64)
+    assert torch.all(y == 0)                     # zero-initialised output conv, as in the public architecture
+    m.out[2].weight.data.normal_(0, 0.02)
+    (g,) = torch.autograd.grad(m(x, torch.tensor([250.0])).square().sum(), x)
+    assert g.shape == x.shape and torch.isfinite(g).all() and float(g.abs().sum()) > 0

@@ -126,8 +126,11 @@ class OpHandle:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
-            _lib._lib.dpsx_op_destroy(h)
+        try:
+            if h and _lib._lib is not None:
+                _lib._lib.dpsx_op_destroy(h)
+        except (AttributeError, TypeError):     # interpreter shutdown: module globals are already gone
+            pass
 
     # -- geometry / scratch
     def out_hw(self, h, w):

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-step best-of-N (search_ddpm) micro-bench: S1 + score + argmin + winner replication, N particles, 256x256."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--operator", default="gaussian_blur")
+    ap.add_argument("--particles", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=30)
+    args = ap.parse_args()
+    from dps_ttc_amd import kernels
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    dev = torch.device("cuda", 0)
+    n = args.particles
+    op, fkw = bench.build_operator(args.operator, dev)
+    smp = create_sampler(sampler="search_ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="")
+    x_t, ring, truth, meas_noise = bench.synth_inputs(n, 2, dev, 1234)
+    yy = op.forward(truth.to(dev), **fkw).detach()
+    y = (yy + meas_noise.to(dev)[..., :yy.shape[-2], :yy.shape[-1]]).contiguous()
+    handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
+    ck = smp.step_coefs[500]
+
+    def step(i, x):
+        s = ring[i % 2]
+        _, sample = kernels.posterior_fwd(x, s["model_out"], s["noise"], ck)
+        costs = handle.score(sample, y)
+        return kernels.replicate(sample, kernels.argmin(costs))
+
+    x = x_t
+    for i in range(3):
+        x = step(i, x)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        x = step(i, x)
+        b.record()
+    torch.cuda.synchronize()
+    ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    algo = 8 * bench.P_BYTES * n
+    print(f"search step N={n} {args.operator}: avg {ts.mean():.1f} us  min {ts.min():.1f} us  "
+          f"{n / ts.mean() * 1e6:.0f} particle-steps/s  {algo / ts.mean() / 1e3:.0f} GB/s algorithmic (8P/particle)")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,21 @@ __device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld_stream(const float *p, bool nt)
+{
+    if (nt) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void st_stream(float *p, const float4 &v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
 
 template <int RR>
 struct SepGeom {
@@ -69,7 +84,7 @@ template <bool REFLECT>
 __device__ __forceinline__ float4 load_unit(const float *plane, int sy, int gx, int w, bool rowok)
 {
     if (!rowok) return make_float4(0, 0, 0, 0);
-    if (gx >= 0 && gx + 3 < w) return *reinterpret_cast<const float4 *>(plane + (int64_t)sy * w + gx);
+    if (gx >= 0 && gx + 3 < w) return *reinterpret_cast<const float4 *>(plane + (unsigned)(sy * w + gx));  // SGPR base + 32-bit offset
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -77,12 +92,12 @@ __device__ __forceinline__ float4 load_unit(const float *plane, int sy, int gx, 
         bool ok = true;
         if constexpr (REFLECT) sx = clampi(reflect_idx(sx, w), 0, w - 1);
         else ok = sx >= 0 && sx < w;
-        v[e] = ok ? plane[(int64_t)sy * w + sx] : 0.0f;
+        v[e] = ok ? plane[(unsigned)(sy * w + sx)] : 0.0f;
     }
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int RR, bool POST, bool REFLECT>
+template <int RR, bool POST, bool REFLECT, int ORDER = 1>
 __device__ __forceinline__ void load_region_fast(float *s, const int h0, const int w0, const BlurArgs &a,
                                                  const int plane)
 {
@@ -104,6 +119,51 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
     float4 xi[NI], ei[NI], vi[NI], zi[NI], xh[NH], eh[NH];
     int hrr[NH], hcu[NH];
     // ---- issue every load first
+    if constexpr (ORDER == 1 && POST) {
+        // streams with reuse (x_t, eps: a neighbour's halo is this tile's interior) first and grouped per stream,
+        // so both requests for a shared line reach the L2 close together; once-read streams (v, noise) last, nt
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *p = pass ? eps : src;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+                const int gy = h0 + row, gx = w0 + 4 * cu;
+                const int sy = clampi(reflect_idx(gy, h), 0, h - 1);
+                const float4 v = load_unit<true>(p, sy, gx, w, true);
+                if (pass) ei[k] = v; else xi[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                const int hu = threadIdx.x + k * NT;
+                float4 v = make_float4(0, 0, 0, 0);
+                if (hu < G::HALO) {
+                    int rr, cu;
+                    halo_unit<RR>(hu, rr, cu);
+                    const int gy = h0 - RR + rr, gx = w0 - RR + 4 * cu;
+                    const int sy = clampi(reflect_idx(gy, h), 0, h - 1);
+                    v = load_unit<true>(p, sy, gx, w, true);
+                }
+                if (pass) eh[k] = v; else xh[k] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+            const int gy = h0 + row, gx = w0 + 4 * cu;
+            vi[k] = zi[k] = make_float4(0, 0, 0, 0);
+            if (gy < h && gx < w && a.k.add_noise) {
+                vi[k] = ld_stream(vv + (unsigned)(gy * w + gx), true);
+                zi[k] = ld_stream(zz + (unsigned)(gy * w + gx), true);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {     // recomputed after the loads are out: nothing but the data stays live
+            const int hu = threadIdx.x + k * NT;
+            hrr[k] = -1;
+            if (hu < G::HALO) halo_unit<RR>(hu, hrr[k], hcu[k]);
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
@@ -117,8 +177,8 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
             ei[k] = load_unit<true>(eps, sy, gx, w, true);
             vi[k] = zi[k] = make_float4(0, 0, 0, 0);
             if (inimg && a.k.add_noise) {
-                vi[k] = *reinterpret_cast<const float4 *>(vv + (int64_t)gy * w + gx);
-                zi[k] = *reinterpret_cast<const float4 *>(zz + (int64_t)gy * w + gx);
+                vi[k] = ld_stream(vv + (int64_t)gy * w + gx, true);
+                zi[k] = ld_stream(zz + (int64_t)gy * w + gx, true);
             }
         }
     }
@@ -138,6 +198,7 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
             xh[k] = load_unit<REFLECT>(src, sy, gx, w, rowok);
             if constexpr (POST) eh[k] = load_unit<true>(eps, sy, gx, w, true);
         }
+    }
     }
     // ---- interior: S1 outputs + LDS
 #pragma unroll
@@ -180,6 +241,127 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
             val.w = post_x0(xh[k].w, eh[k].w, a.k, b);
         }
         *reinterpret_cast<float4 *>(s + hrr[k] * G::SW + 4 * hcu[k]) = val;
+    }
+}
+
+// ---- loader for REGULAR geometry: h % TH == 0, w % TW == 0, RR < min(h, w).  Every tile is full and
+// every float4 unit lies wholly inside or wholly outside the image, so each unit is exactly one
+// unconditional 16-byte load (a wholly reflected unit is the mirrored unit read backwards; a wholly
+// zero-extended one reads a clamped address and is zeroed) -- no divergent branch, no per-element path,
+// hence nothing for the compiler to serialise: all loads issue back to back, one wait.
+typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool REFLECT>
+__device__ __forceinline__ float4 load_unit_reg(const float *plane, int gy, int gx, int h, int w)
+{
+    const bool outx = gx < 0 || gx >= w, outy = gy < 0 || gy >= h;
+    int sy, sx;
+    if constexpr (REFLECT) {
+        sy = gy < 0 ? -gy : (gy >= h ? 2 * (h - 1) - gy : gy);
+        sx = gx < 0 ? -gx - 3 : (gx >= w ? 2 * w - 5 - gx : gx);
+    } else {
+        sy = clampi(gy, 0, h - 1);
+        sx = clampi(gx, 0, w - 4);
+    }
+    const v4fu v = *reinterpret_cast<const v4fu *>(plane + (unsigned)(sy * w + sx));
+    if constexpr (REFLECT) return outx ? make_float4(v.w, v.z, v.y, v.x) : make_float4(v.x, v.y, v.z, v.w);
+    else return (outx || outy) ? make_float4(0, 0, 0, 0) : make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int RR, bool POST, bool REFLECT>
+__device__ __forceinline__ void load_region_reg(float *s, const int h0, const int w0, const BlurArgs &a,
+                                                const int plane)
+{
+    using G = SepGeom<RR>;
+    const int h = a.h, w = a.w;
+    const unsigned hw = (unsigned)(h * w);
+    const int n = plane / a.c, ch = plane % a.c;
+    const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+    if constexpr (POST) {
+        src = a.x_t + (int64_t)plane * hw;
+        eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * hw;
+        vv = eps + (int64_t)a.c * hw;
+        zz = a.noise + (int64_t)plane * hw;
+    } else {
+        src = a.x + (int64_t)plane * hw;
+    }
+    constexpr int NI = TH * TW / 4 / NT;  // interior units per thread (4)
+    constexpr int NH = G::HALO_PER_THREAD;
+    float4 xi[NI], ei[NI], vi[NI], zi[NI], xh[NH], eh[NH];
+    // streams with reuse first and grouped per stream (a neighbour's halo is this tile's interior: both
+    // requests for a shared line then reach the L2 close together); once-read streams last, non-temporal
+#pragma unroll
+    for (int pass = 0; pass < (POST ? 2 : 1); ++pass) {
+        const float *p = pass ? eps : src;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+            const float4 v = *reinterpret_cast<const float4 *>(p + (unsigned)((h0 + row) * w + w0 + 4 * cu));
+            if (pass) ei[k] = v; else xi[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            const int hu = min(threadIdx.x + k * NT, G::HALO - 1);   // surplus lanes repeat the last unit
+            int rr, cu;
+            halo_unit<RR>(hu, rr, cu);
+            const float4 v = load_unit_reg<REFLECT || POST>(p, h0 - RR + rr, w0 - RR + 4 * cu, h, w);
+            if (pass) eh[k] = v; else xh[k] = v;
+        }
+    }
+    if constexpr (POST) {
+        if (a.k.add_noise) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+                const unsigned o = (unsigned)((h0 + row) * w + w0 + 4 * cu);
+                vi[k] = ld_stream(vv + o, true);
+                zi[k] = ld_stream(zz + o, true);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) vi[k] = zi[k] = make_float4(0, 0, 0, 0);
+        }
+    }
+    // ---- interior: S1 outputs + LDS
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+        float4 val = xi[k];
+        if constexpr (POST) {
+            bool b0, b1, b2, b3;
+            float4 x0, sm;
+            x0.x = post_x0(xi[k].x, ei[k].x, a.k, b0);
+            x0.y = post_x0(xi[k].y, ei[k].y, a.k, b1);
+            x0.z = post_x0(xi[k].z, ei[k].z, a.k, b2);
+            x0.w = post_x0(xi[k].w, ei[k].w, a.k, b3);
+            sm.x = post_sample(xi[k].x, x0.x, vi[k].x, zi[k].x, a.k);
+            sm.y = post_sample(xi[k].y, x0.y, vi[k].y, zi[k].y, a.k);
+            sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
+            sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
+            const int64_t o = (int64_t)plane * hw + (unsigned)((h0 + row) * w + w0 + 4 * cu);
+            *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+            *reinterpret_cast<float4 *>(a.sample + o) = sm;
+            *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
+            val = x0;
+        }
+        *reinterpret_cast<float4 *>(s + (RR + row) * G::SW + RR + 4 * cu) = val;
+    }
+    // ---- halo: x0_hat recomputed from the neighbours' x_t / eps (served by L2)
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const int hu = threadIdx.x + k * NT;
+        if (hu >= G::HALO) continue;
+        int rr, cu;
+        halo_unit<RR>(hu, rr, cu);
+        float4 val = xh[k];
+        if constexpr (POST) {
+            bool b;
+            val.x = post_x0(xh[k].x, eh[k].x, a.k, b);
+            val.y = post_x0(xh[k].y, eh[k].y, a.k, b);
+            val.z = post_x0(xh[k].z, eh[k].z, a.k, b);
+            val.w = post_x0(xh[k].w, eh[k].w, a.k, b);
+        }
+        *reinterpret_cast<float4 *>(s + rr * G::SW + 4 * cu) = val;
     }
 }
 
@@ -354,18 +536,43 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    if (!(a.dbg & 4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
+    const bool regular = a.h % TH == 0 && a.w % TW == 0 && RR < a.h && RR < a.w && !(a.dbg & 128);
+    if (regular) load_region_reg<RR, POST, true>(s, h0, w0, a, plane);
+    else if (!(a.dbg & 4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
     else for (int i = threadIdx.x; i < G::RH * G::SW; i += NT) s[i] = (float)i;
     __syncthreads();
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int ox = w0 + 4 * cg;
+    // full tiles fetch their measurement rows now, so the loads fly under the two convolution passes
+    const bool full = RESID && h0 + TH <= a.h && w0 + TW <= a.w && !(a.dbg & 64);
+    float4 yv[4];
+    const int64_t hw = (int64_t)a.h * a.w;
+    if constexpr (RESID) {
+        if (full) {
+            const int n = plane / a.c, ch = plane % a.c;
+            const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + (int64_t)(h0 + 4 * rg) * a.w + ox;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yv[i] = *reinterpret_cast<const float4 *>(yp + (int64_t)i * a.w);
+        }
+    }
     if (!(a.dbg & 1)) hpass_inplace<RR>(s, taps.h);
     __syncthreads();
-    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     float acc[4][4];
     if (!(a.dbg & 2)) vpass_regs<RR>(s, acc, rg, cg, taps.v);
     else for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e];
-    const int ox = w0 + 4 * cg;
     float ss = 0.0f;
-    if (ox < a.w && !(a.dbg & 8)) {
+    if (RESID && full) {
+        if (!(a.dbg & 8)) {
+            float *rp = a.out ? a.out + (int64_t)plane * hw + (int64_t)(h0 + 4 * rg) * a.w + ox : nullptr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 r;
+                r.x = yv[i].x - acc[i][0]; r.y = yv[i].y - acc[i][1]; r.z = yv[i].z - acc[i][2]; r.w = yv[i].w - acc[i][3];
+                if (rp) *reinterpret_cast<float4 *>(rp + (int64_t)i * a.w) = r;
+                ss += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;   // same order as resid_epilogue
+            }
+        }
+    } else if (ox < a.w && !(a.dbg & 8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = h0 + 4 * rg + i;
@@ -416,7 +623,9 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
             s_th[i] = taps.h[i];
             s_tv[i] = taps.v[i];
         }
-    if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
+    const bool regular = a.h % TH == 0 && a.w % TW == 0 && !(a.dbg & 128);
+    if (regular) load_region_reg<RR, false, false>(s, h0, w0, a, plane);
+    else if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
     __syncthreads();
     if constexpr (EPI) {
         const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_th[160];

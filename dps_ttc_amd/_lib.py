@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libdpsx.so")
+# DPSX_LIB: development aid to A/B an experimental build of the same library (tools/abl.sh)
+SO_PATH = os.environ.get("DPSX_LIB") or os.path.join(_HERE, "lib", "libdpsx.so")
 
 OK, EINVAL, EUNSUPPORTED, ELAUNCH, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
 KIND_TAPS, KIND_SEP, KIND_RESIZE, KIND_MASK, KIND_IDENT, KIND_PHASE = range(6)

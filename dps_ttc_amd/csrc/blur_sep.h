@@ -54,29 +54,19 @@ struct SepGeom {
     static constexpr int FOLD_PER_THREAD = (RH * 2 * RR + NT - 1) / NT;
 };
 
+// halo unit hu in [0, HALO) -> (region row rr, float4 column cu); branch-free.  [0, 2 HALO_TB): the RR rows
+// above and the RR rows below the tile, RWU units each; the rest: TH rows x (RR/4 left + RR/4 right) units.
 template <int RR>
 __device__ __forceinline__ void halo_unit(int hu, int &rr, int &cu)
 {
     using G = SepGeom<RR>;
-    if (hu < G::HALO_TB) {
-        rr = hu / G::RWU;
-        cu = hu - rr * G::RWU;
-    } else if (hu < 2 * G::HALO_TB) {
-        hu -= G::HALO_TB;
-        rr = hu / G::RWU;
-        cu = hu - rr * G::RWU;
-        rr += TH + RR;
-    } else if (hu < 2 * G::HALO_TB + G::HALO_LR) {
-        hu -= 2 * G::HALO_TB;
-        rr = hu / (RR / 4);
-        cu = hu - rr * (RR / 4);
-        rr += RR;
-    } else {
-        hu -= 2 * G::HALO_TB + G::HALO_LR;
-        rr = hu / (RR / 4);
-        cu = hu - rr * (RR / 4) + (RR + TW) / 4;
-        rr += RR;
-    }
+    constexpr int Q = RR / 4;
+    const unsigned t = (unsigned)hu, v = (unsigned)max(hu - 2 * G::HALO_TB, 0);
+    const unsigned r_tb = t / G::RWU, c_tb = t - r_tb * G::RWU;
+    const unsigned r_lr = v / (2 * Q), c_lr = v - r_lr * (2 * Q);
+    const bool tb = hu < 2 * G::HALO_TB;
+    rr = tb ? (int)(r_tb < RR ? r_tb : r_tb + TH) : (int)r_lr + RR;
+    cu = tb ? (int)c_tb : (int)(c_lr < Q ? c_lr : c_lr + (TW / 4));
 }
 
 // load one float4 unit of a plane at image row gy (already mapped), columns gx..gx+3
@@ -250,6 +240,7 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
 // zero-extended one reads a clamped address and is zeroed) -- no divergent branch, no per-element path,
 // hence nothing for the compiler to serialise: all loads issue back to back, one wait.
 typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+__device__ float g_zero_unit[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // never written; non-const keeps it a global-space pointer
 
 template <bool REFLECT>
 __device__ __forceinline__ float4 load_unit_reg(const float *plane, int gy, int gx, int h, int w)
@@ -263,9 +254,12 @@ __device__ __forceinline__ float4 load_unit_reg(const float *plane, int gy, int 
         sy = clampi(gy, 0, h - 1);
         sx = clampi(gx, 0, w - 4);
     }
-    const v4fu v = *reinterpret_cast<const v4fu *>(plane + (unsigned)(sy * w + sx));
+    const float *p = plane + (unsigned)(sy * w + sx);
+    // zero extension: a unit outside the image reads a block of zeros -- the load itself stays unconditional
+    if constexpr (!REFLECT) p = (outx || outy) ? g_zero_unit : p;
+    const v4fu v = *reinterpret_cast<const v4fu *>(p);
     if constexpr (REFLECT) return outx ? make_float4(v.w, v.z, v.y, v.x) : make_float4(v.x, v.y, v.z, v.w);
-    else return (outx || outy) ? make_float4(0, 0, 0, 0) : make_float4(v.x, v.y, v.z, v.w);
+    else return make_float4(v.x, v.y, v.z, v.w);
 }
 
 template <int RR, bool POST, bool REFLECT>
@@ -301,7 +295,7 @@ __device__ __forceinline__ void load_region_reg(float *s, const int h0, const in
         }
 #pragma unroll
         for (int k = 0; k < NH; ++k) {
-            const int hu = min(threadIdx.x + k * NT, G::HALO - 1);   // surplus lanes repeat the last unit
+            const int hu = min((int)threadIdx.x + k * NT, G::HALO - 1);   // surplus lanes repeat the last unit
             int rr, cu;
             halo_unit<RR>(hu, rr, cu);
             const float4 v = load_unit_reg<REFLECT || POST>(p, h0 - RR + rr, w0 - RR + 4 * cu, h, w);
@@ -322,6 +316,7 @@ __device__ __forceinline__ void load_region_reg(float *s, const int h0, const in
             for (int k = 0; k < NI; ++k) vi[k] = zi[k] = make_float4(0, 0, 0, 0);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);   // every load above issues before the first use below
     // ---- interior: S1 outputs + LDS
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -543,32 +538,27 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
     __syncthreads();
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ox = w0 + 4 * cg;
-    // full tiles fetch their measurement rows now, so the loads fly under the two convolution passes
-    const bool full = RESID && h0 + TH <= a.h && w0 + TW <= a.w && !(a.dbg & 64);
-    float4 yv[4];
-    const int64_t hw = (int64_t)a.h * a.w;
-    if constexpr (RESID) {
-        if (full) {
-            const int n = plane / a.c, ch = plane % a.c;
-            const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + (int64_t)(h0 + 4 * rg) * a.w + ox;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) yv[i] = *reinterpret_cast<const float4 *>(yp + (int64_t)i * a.w);
-        }
-    }
     if (!(a.dbg & 1)) hpass_inplace<RR>(s, taps.h);
     __syncthreads();
     float acc[4][4];
     if (!(a.dbg & 2)) vpass_regs<RR>(s, acc, rg, cg, taps.v);
     else for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e];
     float ss = 0.0f;
-    if (RESID && full) {
+    if (RESID && regular) {
+        // straight-line epilogue: the four measurement rows are fetched together (one wait), then r = y - A(x0_hat)
         if (!(a.dbg & 8)) {
-            float *rp = a.out ? a.out + (int64_t)plane * hw + (int64_t)(h0 + 4 * rg) * a.w + ox : nullptr;
+            const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + 4 * rg) * a.w + ox);
+            const int n = plane / a.c, ch = plane % a.c;
+            const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + o;
+            float *rp = a.out ? a.out + (int64_t)plane * hw + o : nullptr;
+            float4 yv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yv[i] = *reinterpret_cast<const float4 *>(yp + (unsigned)(i * a.w));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float4 r;
                 r.x = yv[i].x - acc[i][0]; r.y = yv[i].y - acc[i][1]; r.z = yv[i].z - acc[i][2]; r.w = yv[i].w - acc[i][3];
-                if (rp) *reinterpret_cast<float4 *>(rp + (int64_t)i * a.w) = r;
+                if (rp) *reinterpret_cast<float4 *>(rp + (unsigned)(i * a.w)) = r;
                 ss += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;   // same order as resid_epilogue
             }
         }
@@ -609,7 +599,13 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
     float coef = 0.0f;
-    if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_th + 160); }
+    const bool regular = a.h % TH == 0 && a.w % TW == 0 && !(a.dbg & 128);
+    const bool norm_split = EPI && !a.norm_in && regular && a.norm_parts <= 4 * kWave;
+    NormPartials np;
+    if constexpr (EPI) {
+        if (norm_split) np = particle_norm_issue(a.norm_partials, a.norm_parts, plane / a.c);
+        else if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_th + 160);
+    }
     // ---- which folds does this tile need (all block-uniform)
     const bool lfold = reach > 0 && w0 == 0, rfold = reach > 0 && w0 + TW >= a.w - 1 - reach;
     const bool tfold = reach > 0 && h0 == 0, bfold = reach > 0 && h0 + TH >= a.h - 1 - reach;
@@ -623,9 +619,17 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
             s_th[i] = taps.h[i];
             s_tv[i] = taps.v[i];
         }
-    const bool regular = a.h % TH == 0 && a.w % TW == 0 && !(a.dbg & 128);
+    uchar4 gate[4];
+    if (EPI && regular) {
+        // the clamp gate of this lane's 4 x 4 outputs: four bytes per row, fetched with the tile (4 VGPRs)
+        const uint8_t *ip = a.inside_r + (int64_t)plane * a.h * a.w +
+                            (unsigned)((h0 + 4 * (threadIdx.x >> 4)) * a.w + w0 + 4 * (threadIdx.x & 15));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gate[i] = *reinterpret_cast<const uchar4 *>(ip + (unsigned)(i * a.w));
+    }
     if (regular) load_region_reg<RR, false, false>(s, h0, w0, a, plane);
     else if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
+    if constexpr (EPI) { if (norm_split) particle_norm_reduce(np, a.norm_parts, s_th + 160); }
     __syncthreads();
     if constexpr (EPI) {
         const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_th[160];
@@ -718,7 +722,23 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
         }
     }
     const int ox = w0 + 4 * cg;
-    if (ox < a.w && !(a.dbg & 8)) {
+    if (EPI && regular) {
+        if (!(a.dbg & 8)) {
+            const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + 4 * rg) * a.w + ox);
+            const int n = plane / a.c, ch = plane % a.c;
+            float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
+            const float mb = -a.k.b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 g;
+                g.x = gate[i].x ? mb * (coef * acc[i][0]) : 0.0f;
+                g.y = gate[i].y ? mb * (coef * acc[i][1]) : 0.0f;
+                g.z = gate[i].z ? mb * (coef * acc[i][2]) : 0.0f;
+                g.w = gate[i].w ? mb * (coef * acc[i][3]) : 0.0f;
+                *reinterpret_cast<float4 *>(gp + (unsigned)(i * a.w)) = g;
+            }
+        }
+    } else if (ox < a.w && !(a.dbg & 8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
     }

@@ -109,6 +109,32 @@ __device__ __forceinline__ void particle_norm_to_lds(const float *partials, int 
     }
 }
 
+// The same value in two halves, so the partial loads fly together with the caller's tile loads instead of
+// costing a memory round trip at the top of every block: *_issue starts them (wave 0, <= 4 per lane, fixed
+// slots), *_reduce adds them in the order of the loop above (adding the +0.0 of an absent slot is exact).
+// Only for parts <= 4 * kWave (block-uniform test by the caller).
+struct NormPartials { float v[4]; };
+__device__ __forceinline__ NormPartials particle_norm_issue(const float *partials, int parts, int64_t n)
+{
+    NormPartials p;
+    const float *base = partials + n * parts;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)      // every lane loads (clamped address): no branch, nothing waits here
+        p.v[j] = base[min((int)(threadIdx.x & (kWave - 1)) + j * kWave, parts - 1)];
+    return p;
+}
+__device__ __forceinline__ void particle_norm_reduce(const NormPartials &p, int parts, float *slot)
+{
+    if (threadIdx.x < kWave) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += (int)threadIdx.x + j * kWave < parts ? (double)p.v[j] : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+        if (threadIdx.x == 0) *slot = (float)sqrt(acc);
+    }
+}
+
 // ReflectionPad2d index map (no edge repeat); valid while |overhang| < n.
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {

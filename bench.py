@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--operator", default="gaussian_blur", choices=["gaussian_blur", "motion_blur",
                                                                     "super_resolution", "inpainting"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-particles", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
 
 

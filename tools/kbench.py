@@ -44,12 +44,14 @@ def main():
     cases = {
         "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck),
                 (7 + rho) * P),
-        "bwd": (lambda i: kernels.step_bwd(handle, buf, y, 0.3, 1, ck), (4 + rho) * P),
+        "bwd": (lambda i: (setattr(buf, "norm_ready", False), kernels.step_bwd(handle, buf, y, 0.3, 1, ck)),
+                (4 + rho) * P),     # as in the loop: the norm is finalised from the forward half's partials
         "upd": (lambda i: kernels.step_update(buf, ring[i % 2]["g_unet"], ck), 4 * P),
         "op": (lambda i: handle.forward(x_t), (1 + rho) * P),
         "adj": (lambda i: handle.adjoint(u, x=x_t, in_hw=(256, 256)), (1 + rho) * P),
         "score": (lambda i: handle.score(x_t, y), 1 * P),
     }
+    cases["fwd"][0](0)           # partial sums for a stand-alone "bwd"
     for name in args.only.split(","):
         fn, bytes_pp = cases[name]
         for i in range(3):

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 counter CSVs of tools/profile_round.sh into per-launch HBM bytes.
 
-    python tools/parse_pmc.py <fetch_dir> <write_dir> <stats_dir>
+    python tools/parse_pmc.py <fetch_dir> <write_dir> <stats_dir> [<rdreq_dir>]
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts
 exactly half of the bytes of a wide (16 B / lane) coalesced read -> doubled here; WRITE_SIZE is exact for
 16 B / lane streaming stores.  Prints a JSON object {launch: {"fetch_bytes", "write_bytes", "hbm_bytes",
 "avg_ns"}} keyed by the fused launch it belongs to (fwd / bwd / upd), plus the raw kernel names.
+With <rdreq_dir> (TCC_EA0_RDREQ_{32B,64B,128B}_sum) it adds "fetch_bytes_by_request_size", the exact fabric
+read bytes, as a cross-check of the doubled FETCH_SIZE.
 """
 import collections
 import csv
@@ -42,6 +44,11 @@ def main():
     for f in glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             stats[r["Name"]] = float(r["AverageNs"])
+    rd = {}
+    if len(sys.argv) > 4:
+        for size, cname in ((32, "TCC_EA0_RDREQ_32B_sum"), (64, "TCC_EA0_RDREQ_64B_sum"), (128, "TCC_EA0_RDREQ_128B_sum")):
+            for name, vals in counters(sys.argv[4], cname).items():
+                rd[name] = rd.get(name, 0.0) + size * sum(vals) / len(vals)
     res = {}
     for name in sorted(set(fetch) | set(write)):
         role = role_of(name)
@@ -51,6 +58,8 @@ def main():
         wb = 1024.0 * sum(write.get(name, [0])) / max(len(write.get(name, [0])), 1)
         res[role] = {"kernel": name, "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
                      "avg_ns_in_bench": stats.get(name)}
+        if name in rd:
+            res[role]["fetch_bytes_by_request_size"] = rd[name]
     print(json.dumps(res, indent=1))
 
 

@@ -45,7 +45,7 @@ int dpsx_posterior_fwd_f32(const float *x_t, const float *model_out, const float
     if (!coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
     if (n == 0 || chw == 0) return DPSX_OK;   // empty particle set: nothing to do (pointers may be null)
     if (!x_t || !model_out) return DPSX_EINVAL;
-    if (coefs_host->add_noise && !noise) return DPSX_EINVAL;
+    if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
     return posterior_fwd(x_t, model_out, noise, x0_hat, sample, inside, n, chw, to_coefs(coefs_host),
                          (hipStream_t)stream);
 }
@@ -57,7 +57,7 @@ int dpsx_posterior_bwd_f32(const float *g_x0, const float *g_sample, const float
     if (!coefs_host || n < 0 || chw < 0) return DPSX_EINVAL;
     if (n == 0 || chw == 0) return DPSX_OK;
     if (!x_t || !model_out || !g_x || !g_model_out) return DPSX_EINVAL;
-    if (coefs_host->add_noise && g_sample && !noise) return DPSX_EINVAL;
+    if ((coefs_host->add_noise & 1) && g_sample && !noise) return DPSX_EINVAL;
     return posterior_bwd(g_x0, g_sample, x_t, model_out, noise, g_x, g_model_out, n, chw, to_coefs(coefs_host),
                          (hipStream_t)stream);
 }
@@ -414,7 +414,7 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
     if (!x_t || !model_out || !y || !x0_hat || !sample || !inside || !resid || !coefs_host) return DPSX_EINVAL;
-    if (coefs_host->add_noise && !noise) return DPSX_EINVAL;
+    if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
     if (y_n != 1 && y_n != n) return DPSX_EINVAL;
     if (n == 0) return DPSX_OK;
     Ws ws;

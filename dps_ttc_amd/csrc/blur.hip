@@ -144,15 +144,15 @@ __device__ __forceinline__ void load_region(float *s_in, const int SW, const int
                     float vq[U], zq[U];
                     if constexpr (VEC) {
                         float4 t4 = make_float4(0, 0, 0, 0), z4 = t4;
-                        if (a.k.add_noise) {
+                        if (a.k.add_noise & 1) {
                             t4 = *reinterpret_cast<const float4 *>(vv + o);
                             z4 = *reinterpret_cast<const float4 *>(zz + o);
                         }
                         vq[0] = t4.x; vq[1] = t4.y; vq[2] = t4.z; vq[3] = t4.w;
                         zq[0] = z4.x; zq[1] = z4.y; zq[2] = z4.z; zq[3] = z4.w;
                     } else {
-                        vq[0] = a.k.add_noise ? vv[o] : 0.0f;
-                        zq[0] = a.k.add_noise ? zz[o] : 0.0f;
+                        vq[0] = (a.k.add_noise & 1) ? vv[o] : 0.0f;
+                        zq[0] = (a.k.add_noise & 1) ? zz[o] : 0.0f;
                     }
 #pragma unroll
                     for (int e = 0; e < U; ++e) sm[e] = post_sample(xin[e], val[e], vq[e], zq[e], a.k);

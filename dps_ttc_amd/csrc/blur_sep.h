@@ -142,7 +142,7 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
             const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
             const int gy = h0 + row, gx = w0 + 4 * cu;
             vi[k] = zi[k] = make_float4(0, 0, 0, 0);
-            if (gy < h && gx < w && a.k.add_noise) {
+            if (gy < h && gx < w && (a.k.add_noise & 1)) {
                 vi[k] = ld_stream(vv + (unsigned)(gy * w + gx), true);
                 zi[k] = ld_stream(zz + (unsigned)(gy * w + gx), true);
             }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
         if constexpr (POST) {
             ei[k] = load_unit<true>(eps, sy, gx, w, true);
             vi[k] = zi[k] = make_float4(0, 0, 0, 0);
-            if (inimg && a.k.add_noise) {
+            if (inimg && (a.k.add_noise & 1)) {
                 vi[k] = ld_stream(vv + (int64_t)gy * w + gx, true);
                 zi[k] = ld_stream(zz + (int64_t)gy * w + gx, true);
             }
@@ -303,7 +303,7 @@ __device__ __forceinline__ void load_region_reg(float *s, const int h0, const in
         }
     }
     if constexpr (POST) {
-        if (a.k.add_noise) {
+        if (a.k.add_noise & 1) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;

@@ -62,8 +62,16 @@ __device__ __forceinline__ float post_logvar(float v, const Coefs &c)
     return __fadd_rn(__fmul_rn(frac, c.max_log), __fmul_rn(__fsub_rn(1.0f, frac), c.min_log));
 }
 
+// add_noise: bit 0 = add the noise term (t != 0); bit 1 = DDIM step (gaussian_diffusion.py:479-509) with
+// c1 = sqrt(abar_prev), c2 = sqrt(1 - abar_prev - sigma^2), min_log = sigma; eps is re-derived from the
+// clamped x0_hat as predict_eps_from_x_start does (:506-509), one rounding per reference op.
 __device__ __forceinline__ float post_sample(float x, float x0, float v, float z, const Coefs &c)
 {
+    if (c.add_noise & 2) {
+        const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c.a, x), x0), c.b);
+        const float mean = __fadd_rn(__fmul_rn(x0, c.c1), __fmul_rn(c.c2, eps));
+        return (c.add_noise & 1) ? __fadd_rn(mean, __fmul_rn(c.min_log, z)) : mean;
+    }
     float mean = __fadd_rn(__fmul_rn(c.c1, x0), __fmul_rn(c.c2, x));
     if (!c.add_noise) return mean;
     // exp(x) = 2^(x log2 e) on the transcendental unit (v_exp_f32); |x| <= ~10 here, error ~4e-7 relative

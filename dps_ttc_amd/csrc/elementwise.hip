@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kThreads) void k_posterior_fwd(const float *__restr
         const float4 xv = *reinterpret_cast<const float4 *>(xp);
         const float4 ev = *reinterpret_cast<const float4 *>(ep);
         float4 vv = make_float4(0, 0, 0, 0), zv = vv;
-        if (k.add_noise) {
+        if (k.add_noise & 1) {
             vv = *reinterpret_cast<const float4 *>(vp);
             zv = *reinterpret_cast<const float4 *>(z + o);
         }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void k_posterior_fwd(const float *__restr
     } else {
         bool b;
         float x0 = post_x0(*xp, *ep, k, b);
-        float sm = post_sample(*xp, x0, k.add_noise ? *vp : 0.f, k.add_noise ? z[o] : 0.f, k);
+        float sm = post_sample(*xp, x0, (k.add_noise & 1) ? *vp : 0.f, (k.add_noise & 1) ? z[o] : 0.f, k);
         if (x0o) x0o[o] = x0;
         if (so) so[o] = sm;
         if (ins) ins[o] = b;
@@ -92,12 +92,15 @@ __global__ __launch_bounds__(kThreads) void k_posterior_bwd(const float *__restr
     bool in;
     (void)post_x0(x[o], mo[e], k, in);
     const float gs = g_s ? g_s[o] : 0.0f;
-    const float g0 = (g_x0 ? g_x0[o] : 0.0f) + k.c1 * gs;
+    // d sample / d x0_hat and d sample / d x (direct): DDPM c1, c2;  DDIM c1 - c2 / b, c2 a / b
+    const bool ddim = k.add_noise & 2;
+    const float ds_dx0 = ddim ? k.c1 - k.c2 / k.b : k.c1, ds_dx = ddim ? k.c2 * k.a / k.b : k.c2;
+    const float g0 = (g_x0 ? g_x0[o] : 0.0f) + ds_dx0 * gs;
     const float gp = in ? g0 : 0.0f;
-    g_x[o] = k.a * gp + k.c2 * gs;
+    g_x[o] = k.a * gp + ds_dx * gs;
     g_mo[e] = -k.b * gp;
     float gv = 0.0f;
-    if (k.add_noise && g_s) {
+    if (k.add_noise == 1 && g_s) {
         const float sd = expf(0.5f * post_logvar(mo[e + chw], k));
         gv = gs * z[o] * sd * (0.25f * (k.max_log - k.min_log));
     }
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const
         const float4 xv = *reinterpret_cast<const float4 *>(a.x_t + o);
         const float4 ev = *reinterpret_cast<const float4 *>(a.model_out + e);
         float4 vv = make_float4(0, 0, 0, 0), zv = vv;
-        if (a.k.add_noise) {
+        if (a.k.add_noise & 1) {
             vv = *reinterpret_cast<const float4 *>(a.model_out + e + chw);
             zv = *reinterpret_cast<const float4 *>(a.noise + o);
         }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
                 const int rr = u / wu, cu = u - rr * wu;
                 const int gy = lo + rr;
                 const int64_t o = (int64_t)gy * d.in_w + cu * U;
-                const bool own = POST && gy >= olo && gy < ohi && a.k.add_noise;
+                const bool own = POST && gy >= olo && gy < ohi && (a.k.add_noise & 1);
                 if constexpr (VEC) {
                     const float4 t = *reinterpret_cast<const float4 *>(src + o);
                     xv[bb][0] = t.x; xv[bb][1] = t.y; xv[bb][2] = t.z; xv[bb][3] = t.w;

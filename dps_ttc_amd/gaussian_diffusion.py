@@ -200,6 +200,10 @@ class GaussianDiffusion:
     def p_sample(self, model, x, t):
         raise NotImplementedError
 
+    def sample_coefs(self, idx):
+        """struct dpsx_coefs of this sampler's step at loop index idx (DDPM record; DDIM overrides)"""
+        return self.step_coefs[idx]
+
     def _scale_timesteps(self, t):
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
 
@@ -217,7 +221,7 @@ class GaussianDiffusion:
         return None, kw
 
     def _fusion_plan(self, measurement_cond_fn, x_start):
-        if not (self.hip_posterior and isinstance(self, DDPM)):
+        if not (self.hip_posterior and isinstance(self, (DDPM, DDIM))):
             return None
         method, kw = self._unwrap_cond_fn(measurement_cond_fn)
         if method is None or method.fused_spec(**kw) is None:
@@ -248,7 +252,7 @@ class GaussianDiffusion:
         mo = kernels.f32c(model_out.detach(), "model output")
         if mo.shape[1] != 2 * x_prev.shape[1]:
             raise ValueError("the fused DPS step needs a learned-sigma model ([N, 2C, H, W] output)")
-        coefs = self.step_coefs[idx]
+        coefs = self.sample_coefs(idx)
         if noise is None:
             noise = self._randn(x_prev)
         buf = self._buffers(handle, x_prev)
@@ -375,9 +379,30 @@ class DDPM(SpacedDiffusion):
 
 @register_sampler(name='ddim')
 class DDIM(SpacedDiffusion):
-    def p_sample(self, model, x, t, eta=0.0):
-        """reference :479-509 (device tensor arithmetic; the DDIM step is a 'next' row of the scope table)"""
+    #: the reference's p_sample takes eta per call and never passes it (:481); kept as the default
+    eta = 0.0
+
+    def sample_coefs(self, idx, eta=None):
+        eta = self.eta if eta is None else eta
+        key = (idx, float(eta))
+        cache = self.__dict__.setdefault('_ddim_coefs', {})
+        if key not in cache:
+            cache[key] = kernels.make_ddim_coefs(self.sqrt_recip_alphas_cumprod[idx],
+                                                 self.sqrt_recipm1_alphas_cumprod[idx], self.alphas_cumprod[idx],
+                                                 self.alphas_cumprod_prev[idx], eta, idx != 0)
+        return cache[key]
+
+    def p_sample(self, model, x, t, eta=None, noise=None):
+        """reference :479-509.  The noise is drawn whether or not it is used, as there (:493)."""
         idx = int(t)
+        if noise is None:
+            noise = self._randn(x)
+        if self.hip_posterior:
+            model_output = self._call_model(model, x, idx)
+            x0, sample = kernels.PosteriorStepFn.apply(x, model_output, noise, self.sample_coefs(idx, eta))
+            return {'sample': sample, 'pred_xstart': x0}
+        # other mean / variance parameterisations: device tensor arithmetic in the reference's op order
+        eta = self.eta if eta is None else eta
         out = self.p_mean_variance(model, x, t)
         a = float(np.float32(self.sqrt_recip_alphas_cumprod[idx]))
         b = float(np.float32(self.sqrt_recipm1_alphas_cumprod[idx]))
@@ -385,7 +410,6 @@ class DDIM(SpacedDiffusion):
         abar = float(np.float32(self.alphas_cumprod[idx]))
         abar_prev = float(np.float32(self.alphas_cumprod_prev[idx]))
         sigma = eta * math.sqrt((1 - abar_prev) / (1 - abar)) * math.sqrt(1 - abar / abar_prev)
-        noise = self._randn(x)
         sample = out['pred_xstart'] * math.sqrt(abar_prev) + math.sqrt(1 - abar_prev - sigma ** 2) * eps
         if idx != 0:
             sample = sample + sigma * noise
@@ -467,18 +491,31 @@ class TTC_DDIM(DDIM):
         kernels.require_cuda(img, "x_start")
         resample_every_steps, resample_scale = 10, 100
         distance = None
+        # 'ps'-type methods run the three fused launches with the DDIM variant of S1; the rest (e.g. 'mcg', the
+        # method whose two return values fit the reference loop's unpacking at :672) go through the per-op path
+        plan = self._fusion_plan(measurement_cond_fn, img)
         for idx in range(self.num_timesteps - 1, -1, -1):
-            img = img.detach().requires_grad_()
-            out = self.p_sample(x=img, t=torch.tensor([idx], device=img.device), model=model)
-            noisy_measurement = self.q_sample(measurement, t=idx)
-            ret = measurement_cond_fn(x_t=out['sample'], measurement=measurement,
-                                      noisy_measurement=noisy_measurement, x_prev=img, x_0_hat=out['pred_xstart'])
-            img, distance = ret[0].detach(), ret[1].detach()
+            if plan is not None:
+                noise = self._randn(img)
+                if self.rng_parity:
+                    self._randn(measurement, self.parity_measurement_stride)      # q_sample's draw (:668)
+                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise)
+            else:
+                img = img.detach().requires_grad_()
+                out = self.p_sample(x=img, t=torch.tensor([idx], device=img.device), model=model)
+                noisy_measurement = self.q_sample(measurement, t=idx)
+                ret = measurement_cond_fn(x_t=out['sample'], measurement=measurement,
+                                          noisy_measurement=noisy_measurement, x_prev=img,
+                                          x_0_hat=out['pred_xstart'])
+                img, distance = ret[0].detach(), ret[1].detach()
             n = len(distance)
             if n > 1 and idx % resample_every_steps == 0:
                 weights = torch.exp(-distance / resample_scale)
                 if weights.max() != weights.min():
-                    ids = torch.multinomial(weights, n, replacement=True)
+                    # the draw is torch.multinomial (host generator in RNG-replay mode), the gather is HIP
+                    ids = torch.multinomial(weights.cpu(), n, replacement=True).to(img.device) if self.rng_parity \
+                        else torch.multinomial(weights, n, replacement=True)
+                    self.last_resample_ids = ids
                     img = kernels.gather(img, ids)
                     distance = distance[ids]
         return img, distance

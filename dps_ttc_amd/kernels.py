@@ -18,6 +18,16 @@ def make_coefs(a, b, c1, c2, min_log, max_log, add_noise):
     return Coefs(float(a), float(b), float(c1), float(c2), float(min_log), float(max_log), int(bool(add_noise)))
 
 
+def make_ddim_coefs(a, b, abar, abar_prev, eta, add_noise):
+    """struct dpsx_coefs of one DDIM step (reference gaussian_diffusion.py:481-509).  The reference evaluates
+    sigma and the two square roots as fp32 tensor arithmetic on .float()-cast table entries, one rounding per
+    op; numpy float32 scalars reproduce that bit for bit."""
+    one, ab, abp = np.float32(1.0), np.float32(abar), np.float32(abar_prev)
+    sigma = np.float32(eta) * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
+    return Coefs(float(np.float32(a)), float(np.float32(b)), float(np.sqrt(abp)),
+                 float(np.sqrt(one - abp - sigma ** 2)), float(sigma), 0.0, 2 | int(bool(add_noise)))
+
+
 # ------------------------------------------------------------------ S1
 def posterior_fwd(x_t, model_out, noise, coefs, want_inside=False):
     """p_mean_variance + DDPM.p_sample (gaussian_diffusion.py:308-330, 466-476) -> (x0_hat, sample[, inside])."""

@@ -49,7 +49,12 @@ typedef struct dpsx_coefs {
     float c2;       /* posterior_mean_coef2[t]         :117 */
     float min_log;  /* posterior_log_variance_clipped[t]  :235 */
     float max_log;  /* log(betas[t])                   :236 */
-    int32_t add_noise; /* t != 0                       gaussian_diffusion.py:473 */
+    int32_t add_noise; /* bit 0: t != 0 (add the noise term)  gaussian_diffusion.py:473, :503
+                        * bit 1: DDIM step instead of DDPM (DDIM.p_sample, gaussian_diffusion.py:481-509); the
+                        *        record then carries c1 = sqrt(alphas_cumprod_prev[t]),
+                        *        c2 = sqrt(1 - alphas_cumprod_prev[t] - sigma^2), min_log = sigma (eta-scaled, :487-491),
+                        *        max_log unused; a, b as above (also predict_eps_from_x_start, :506-509).
+                        *        The variance channels of model_out are then not read. */
 } dpsx_coefs;
 
 /* ---- S1: p_mean_variance + DDPM.p_sample ----------------------------------

@@ -25,6 +25,7 @@
  *   :110-118 (mean), :230-242 (log-variance), gaussian_diffusion.py:466-476.
  *   model_out is [N, 2C, H, W]: channels [0,C) = eps, [C,2C) = v
  *   (gaussian_diffusion.py:314-315).  `chw` = C*H*W.
+ *   add_noise: bit 0 = add the noise term (t != 0), bit 1 = DDIM step (:479-509) instead of DDPM.
  * ---------------------------------------------------------------------- */
 API void orc_posterior_fwd(const float *x, const float *model_out, const float *noise,
                            float *x0_hat, float *mean, float *logvar, float *sample,
@@ -49,7 +50,17 @@ API void orc_posterior_fwd(const float *x, const float *model_out, const float *
             float l2 = (1.0f - frac) * min_log;
             float lv = l1 + l2;
             float s = mu;
-            if (add_noise) {
+            if (add_noise & 2) {
+                /* DDIM (gaussian_diffusion.py:481-509): c1 = sqrt(abar_prev), c2 = sqrt(1 - abar_prev - sigma^2),
+                 * min_log carries sigma; eps re-derived from x0_hat (:506-509) */
+                float eps = (t1 - x0) / b;
+                float d1 = x0 * c1;
+                float d2 = c2 * eps;
+                mu = d1 + d2;
+                s = mu;
+                if (add_noise & 1) s = mu + min_log * zp[i];
+                lv = 0.0f;
+            } else if (add_noise) {
                 float sd = expf(0.5f * lv);
                 s = mu + sd * zp[i];
             }
@@ -81,12 +92,15 @@ API void orc_posterior_bwd(const float *g_x0, const float *g_sample,
             float pre = a * xp[i] - b * ep[i];
             int in = (pre >= -1.0f && pre <= 1.0f);
             double gs = g_sample ? g_sample[o] : 0.0;
-            double g0 = (g_x0 ? g_x0[o] : 0.0) + (double)c1 * gs;
+            /* DDIM: sample = c1 x0 + c2 (a x - x0) / b (+ sigma z) */
+            double ds_dx0 = (add_noise & 2) ? (double)c1 - (double)c2 / (double)b : (double)c1;
+            double ds_dx = (add_noise & 2) ? (double)c2 * (double)a / (double)b : (double)c2;
+            double g0 = (g_x0 ? g_x0[o] : 0.0) + ds_dx0 * gs;
             double gp = in ? g0 : 0.0;
-            g_x[o] = (float)((double)a * gp + (double)c2 * gs);
+            g_x[o] = (float)((double)a * gp + ds_dx * gs);
             ge[i] = (float)(-(double)b * gp);
             double gvv = 0.0;
-            if (add_noise && g_sample) {
+            if (add_noise == 1 && g_sample) {
                 float frac = (vp[i] + 1.0f) / 2.0f;
                 float lv = frac * max_log + (1.0f - frac) * min_log;
                 gvv = gs * noise[o] * exp(0.5 * (double)lv) * 0.5 * 0.5 *

@@ -110,6 +110,26 @@ def step_coefs(sched, t):
     }
 
 
+def ddim_step_coefs(sched, t, eta=0.0):
+    """The scalars of one DDIM step (gaussian_diffusion.py:481-509) in the same record: c1 = sqrt(abar_prev),
+    c2 = sqrt(1 - abar_prev - sigma^2), min_log = sigma, add_noise = 2 | (t != 0).  The reference evaluates
+    them as fp32 tensor arithmetic on .float()-cast table entries, one rounding per op -- restated here
+    with numpy float32 scalars."""
+    f = lambda key: np.float32(sched[key][t])
+    one = np.float32(1.0)
+    ab, abp = f("alphas_cumprod"), f("alphas_cumprod_prev")
+    sigma = np.float32(eta) * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
+    return {
+        "a": f("sqrt_recip_alphas_cumprod"),
+        "b": f("sqrt_recipm1_alphas_cumprod"),
+        "c1": np.sqrt(abp),
+        "c2": np.sqrt(one - abp - sigma ** 2),
+        "min_log": np.float32(sigma),
+        "max_log": np.float32(0.0),
+        "add_noise": 2 | int(t != 0),
+    }
+
+
 def model_timestep(sched, t, rescale=True):
     """gaussian_diffusion.py:455-463 -- what the wrapped UNet receives as t."""
     v = float(sched["timestep_map"][t])

@@ -300,7 +300,90 @@ def main():
     out["resample.seed"] = np.int64(77)
     out["resample.ids"] = torch.multinomial(wts, 8, replacement=True).numpy().astype(np.int64)
     save("search.npz", **out)
+    ddim_fixtures(GD, CM, MS)
+
+
+def ddim_fixtures(GD, CM, MS):
+    """7. DDIM step (gaussian_diffusion.py:479-509) and the ttc_ddim loop (:644-707) -> ddim.npz"""
+    out = {}
+    with quiet():
+        ddim = GD.create_sampler(sampler="ddim", timestep_respacing="", **DIFF)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, 8, 8, generator=gen)
+    out["x"] = np32(x)
+    out["w_x0"] = np32(torch.randn(2, 3, 8, 8, generator=gen))
+    out["w_s"] = np32(torch.randn(2, 3, 8, 8, generator=gen))
+    for t, eta in ((999, 0.0), (500, 0.0), (1, 0.0), (0, 0.0), (500, 0.5), (0, 0.5)):
+        tag = f"t{t}.eta{eta:g}"
+        a = float(ddim.sqrt_recip_alphas_cumprod[t])
+        b = float(ddim.sqrt_recipm1_alphas_cumprod[t])
+        target = 1.4 * torch.tanh(torch.randn(2, 3, 8, 8, generator=gen))
+        eps = (a * x - target) / b
+        v = torch.rand(2, 3, 8, 8, generator=gen) * 2 - 1
+        mo = torch.cat([eps, v], dim=1).requires_grad_()
+        xx = x.clone().requires_grad_()
+        torch.manual_seed(200 + t)
+        noise = torch.randn_like(xx)
+        torch.manual_seed(200 + t)
+        with quiet():
+            res = ddim.p_sample(model=lambda z, ts: mo, x=xx, t=torch.tensor([t]), eta=eta)
+        loss = (res["pred_xstart"] * torch.from_numpy(out["w_x0"])).sum() + \
+               (res["sample"] * torch.from_numpy(out["w_s"])).sum()
+        gx, gmo = torch.autograd.grad(loss, [xx, mo])
+        out[f"{tag}.model_out"] = np32(mo)
+        out[f"{tag}.noise"] = np32(noise)
+        out[f"{tag}.x0_hat"] = np32(res["pred_xstart"])
+        out[f"{tag}.sample"] = np32(res["sample"])
+        out[f"{tag}.g_x"] = np32(gx)
+        out[f"{tag}.g_model_out"] = np32(gmo)
+
+    # ttc_ddim free-running loop.  Of the shipped conditioning methods only the two-value ones fit the loop's
+    # `img, distance = measurement_cond_fn(...)` (:672): 'mcg' on a blur operator (transpose = identity) is the
+    # combination that runs end to end in the reference.
+    model = StandInModel()
+    noiser = MS.get_noise("gaussian", sigma=0.05)
+    gb = MS.get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device="cpu")
+    for tag, respacing, n, seed, scale in (("gauss.r20", "20", 4, 70, 0.5), ("gauss.r50", "ddim50", 6, 71, 0.3)):
+        with quiet():
+            smp = GD.create_sampler(sampler="ttc_ddim", timestep_respacing=respacing, **DIFF)
+            cm = CM.get_conditioning_method("mcg", gb, noiser, scale=scale)
+        gen = torch.Generator().manual_seed(seed)
+        truth = torch.rand(1, 3, 64, 64, generator=gen) * 2 - 1
+        y = gb.forward(truth)
+        y = y + 0.05 * torch.randn(*y.shape, generator=gen)
+        x_start = torch.randn(n, 3, 64, 64, generator=gen)
+        norms = []
+
+        def cond(**kw):
+            r = cm.conditioning(**kw)
+            norms.append(np32(r[1]))
+            return r
+
+        torch.manual_seed(seed + 1)
+        with quiet() as buf:
+            img, dist = smp.p_sample_loop(model=model, x_start=x_start.clone().requires_grad_(), measurement=y,
+                                          measurement_cond_fn=cond, record=False, save_root=None)
+        ev = re.findall(r"Resampling, ids = tensor\(\[([0-9, ]+)\]\), idx = (\d+)", buf.getvalue())
+        out[f"{tag}.y"] = np32(y)
+        out[f"{tag}.x_start"] = np32(x_start)
+        out[f"{tag}.rng_seed"] = np.int64(seed + 1)
+        out[f"{tag}.final"] = np32(img)
+        out[f"{tag}.distance"] = np32(dist)
+        out[f"{tag}.norms"] = np.stack(norms)
+        out[f"{tag}.resample_idx"] = np.asarray([int(i) for _, i in ev], dtype=np.int64)
+        out[f"{tag}.resample_ids"] = np.asarray([[int(v) for v in ids.split(",")] for ids, _ in ev],
+                                                dtype=np.int64).reshape(len(ev), n)
+    save("ddim.npz", **out)
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-ddim" in sys.argv:       # adds ddim.npz without rewriting the other fixtures
+        install_stubs()
+        with quiet():
+            from guided_diffusion import condition_methods as CM
+            from guided_diffusion import gaussian_diffusion as GD
+            from guided_diffusion import measurements as MS
+        torch.set_num_threads(8)
+        ddim_fixtures(GD, CM, MS)
+    else:
+        main()

@@ -51,6 +51,36 @@ def test_posterior_step_golden(K, oracle, golden, t):
     assert rel_l2(host(gmo), g[f"t{t}.g_model_out"]) < TOL
 
 
+def ddim_coefs_of(K, oracle, t, eta, sched=None):
+    sched = sched or oracle.tables.schedule(1000)
+    c = oracle.tables.ddim_step_coefs(sched, t, eta)
+    ck = K.make_ddim_coefs(sched["sqrt_recip_alphas_cumprod"][t], sched["sqrt_recipm1_alphas_cumprod"][t],
+                           sched["alphas_cumprod"][t], sched["alphas_cumprod_prev"][t], eta, t != 0)
+    return c, ck
+
+
+@pytest.mark.parametrize("t,eta", [(999, 0.0), (500, 0.0), (1, 0.0), (0, 0.0), (500, 0.5), (0, 0.5)])
+def test_ddim_step_golden(K, oracle, golden, t, eta):
+    """DDIM variant of S1 (reference gaussian_diffusion.py:479-509): HIP forward and VJP against the reference"""
+    g = golden("ddim")
+    tag = f"t{t}.eta{eta:g}"
+    c, ck = ddim_coefs_of(K, oracle, t, eta)
+    x0, sample = K.posterior_fwd(dev(g["x"]), dev(g[f"{tag}.model_out"]), dev(g[f"{tag}.noise"]), ck)
+    np.testing.assert_array_equal(host(x0), g[f"{tag}.x0_hat"])
+    assert rel_l2(host(sample), g[f"{tag}.sample"]) < 1e-6
+    o = oracle.posterior_fwd(g["x"], g[f"{tag}.model_out"], g[f"{tag}.noise"], c)
+    np.testing.assert_array_equal(host(sample), o["sample"])               # same op order as the oracle: bit-exact
+    gx, gmo = K.posterior_bwd(dev(g["w_x0"]), dev(g["w_s"]), dev(g["x"]), dev(g[f"{tag}.model_out"]),
+                              dev(g[f"{tag}.noise"]), ck)
+    assert rel_l2(host(gx), g[f"{tag}.g_x"]) < TOL
+    assert rel_l2(host(gmo), g[f"{tag}.g_model_out"]) < TOL
+    # through autograd, as the per-op path uses it
+    xx, mo = dev(g["x"]).requires_grad_(), dev(g[f"{tag}.model_out"]).requires_grad_()
+    x0a, sa = K.PosteriorStepFn.apply(xx, mo, dev(g[f"{tag}.noise"]), ck)
+    ga, gb = torch.autograd.grad((x0a * dev(g["w_x0"])).sum() + (sa * dev(g["w_s"])).sum(), [xx, mo])
+    assert rel_l2(host(ga), g[f"{tag}.g_x"]) < TOL and rel_l2(host(gb), g[f"{tag}.g_model_out"]) < TOL
+
+
 @pytest.mark.parametrize("shape", [(3, 3, 17, 13), (2, 3, 64, 64), (1, 1, 5, 3)])
 def test_posterior_step_ragged_vs_oracle(K, oracle, shape):
     rng = np.random.RandomState(0)
@@ -245,10 +275,10 @@ def test_residual_norm_and_vjp(K, oracle):
 
 
 # ----------------------------------------------------------------- fused DPS step vs oracle
-def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False):
+def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False, ddim_eta=None):
     rng = np.random.RandomState(seed)
     sched = oracle.tables.schedule(1000)
-    c, ck = coefs_of(K, oracle, t, sched)
+    c, ck = coefs_of(K, oracle, t, sched) if ddim_eta is None else ddim_coefs_of(K, oracle, t, ddim_eta, sched)
     op, fkw = make_product_op(name, hw=hw, kernel=kernel, mask=mask)
     orc = make_oracle_op(oracle, name, hw=hw, kernel=kernel, mask=mask)
     x_prev = rng.randn(n, 3, hw, hw).astype(np.float32)
@@ -289,6 +319,15 @@ def test_fused_step_vs_oracle(K, oracle, golden, name, hw, t, power):
     g = golden("operators")
     mask = (np.random.RandomState(7).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
     _fused_case(K, oracle, name, 3, hw, t, 0.7, power, seed=hw + t, kernel=g["motion.kernel"], mask=mask)
+
+
+@pytest.mark.parametrize("name,hw", [("gauss", 64), ("sr4", 64), ("inpaint", 64), ("motion", 64), ("phase", 32)])
+@pytest.mark.parametrize("t,eta", [(900, 0.0), (400, 0.7), (0, 0.0)])
+def test_fused_step_ddim_vs_oracle(K, oracle, golden, name, hw, t, eta):
+    """the same three launches with the DDIM variant of S1 (scope row f2)"""
+    g = golden("operators")
+    mask = (np.random.RandomState(7).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    _fused_case(K, oracle, name, 3, hw, t, 0.7, 1, seed=hw + t + 1, kernel=g["motion.kernel"], mask=mask, ddim_eta=eta)
 
 
 def test_fused_step_full_size_headline(K, oracle):
@@ -384,6 +423,64 @@ def test_base_loop_golden(K, golden, tag, oname, resp, scale, norm_exp, fused):
     assert rel_l2(np.stack(norms), g[f"{tag}.norms"]) < 1e-4
     assert rel_l2(host(img), g[f"{tag}.final"]) < 1e-4
     assert rel_l2(host(dist), g[f"{tag}.norms"][-1]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,resp,scale", [("gauss.r20", "20", 0.5), ("gauss.r50", "ddim50", 0.3)])
+def test_ttc_ddim_loop_golden(K, golden, tag, resp, scale):
+    """ttc_ddim (reference gaussian_diffusion.py:644-707) with 'mcg', the shipped method whose two return values
+    fit the loop: DDIM S1 in HIP, per-op HIP operator calls under autograd, multinomial resampling on the replayed
+    host RNG stream, HIP gather.  Resampled ids bit-exact; images and norms within the 1e-4 gate."""
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.measurements import get_noise
+    g = golden("ddim")
+    op, _ = make_product_op("gauss", hw=64)
+    cm = get_conditioning_method("mcg", op, get_noise("gaussian", sigma=0.05), scale=scale)
+    smp = _sampler("ttc_ddim", resp)
+    norms, picks = [], []
+
+    def cond(**kw):
+        r = cm.conditioning(**kw)
+        norms.append(host(r[1]).copy())
+        return r
+    orig = K.gather
+
+    def spy(x, ids):
+        picks.append(ids.cpu().numpy().copy())
+        return orig(x, ids)
+    K.gather = spy
+    try:
+        torch.manual_seed(int(g[f"{tag}.rng_seed"]))
+        img, dist = smp.p_sample_loop(model=StandInModel().to(DEV), x_start=dev(g[f"{tag}.x_start"]).requires_grad_(),
+                                      measurement=dev(g[f"{tag}.y"]), measurement_cond_fn=cond, record=False,
+                                      save_root=None)
+    finally:
+        K.gather = orig
+    np.testing.assert_array_equal(np.stack(picks), g[f"{tag}.resample_ids"])
+    assert rel_l2(np.stack(norms), g[f"{tag}.norms"]) < 1e-4
+    assert rel_l2(host(img), g[f"{tag}.final"]) < 1e-4
+    assert rel_l2(host(dist), g[f"{tag}.distance"]) < 1e-4
+
+
+def test_ttc_ddim_fused_matches_per_op(K, golden):
+    """'ps' under ttc_ddim (the reference's own loop cannot unpack its three return values): the fused three-launch
+    DDIM step and the per-op autograd path are two HIP routes to the same numbers."""
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.measurements import get_noise
+    g = golden("ddim")
+    op, _ = make_product_op("gauss", hw=64)
+    cm = get_conditioning_method("ps", op, get_noise("gaussian", sigma=0.05), scale=0.5)
+    res = []
+    for fused in (True, False):
+        smp = _sampler("ttc_ddim", "20")
+        cond = cm.conditioning if fused else (lambda **kw: cm.conditioning(**kw))
+        assert (smp._fusion_plan(cond, dev(g["gauss.r20.x_start"])) is not None) == fused
+        torch.manual_seed(5)
+        img, dist = smp.p_sample_loop(model=StandInModel().to(DEV), x_start=dev(g["gauss.r20.x_start"]).requires_grad_(),
+                                      measurement=dev(g["gauss.r20.y"]), measurement_cond_fn=cond, record=False,
+                                      save_root=None)
+        res.append((host(img), host(dist), smp.last_resample_ids.cpu().numpy()))
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert rel_l2(res[0][0], res[1][0]) < 1e-5 and rel_l2(res[0][1], res[1][1]) < 1e-5
 
 
 @pytest.mark.parametrize("tag,oname", [("sr4", "sr4"), ("gauss", "gauss")])

@@ -121,7 +121,16 @@ def test_fused_spec_and_fusion_planning():
     m, kw = GaussianDiffusion._unwrap_cond_fn(lambda **k: None)
     assert m is None
     ddim = create_sampler(sampler="ddim", **DIFF, timestep_respacing="")
-    assert ddim._fusion_plan(ps.conditioning, torch.zeros(1, 3, 64, 64)) is None        # fused step is DDPM only
+    mcg = get_conditioning_method("mcg", op, g)
+    assert ddim._fusion_plan(mcg.conditioning, torch.zeros(1, 3, 64, 64)) is None       # two-value methods: per-op path
+    # the DDIM record of a step: same a, b; c1 = sqrt(abar_prev), c2 = sqrt(1 - abar_prev - sigma^2), min_log = sigma
+    import oracle.tables as T
+    sched = T.schedule(1000)
+    for t, eta in ((999, 0.0), (500, 0.5), (0, 0.0), (0, 0.5)):
+        c, ref = ddim.sample_coefs(t, eta), T.ddim_step_coefs(sched, t, eta)
+        for k in ("a", "b", "c1", "c2", "min_log"):
+            assert np.float32(getattr(c, k)) == np.float32(ref[k]), (t, eta, k)
+        assert c.add_noise == ref["add_noise"] == (2 | int(t != 0))
     other = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="start_x",
                            model_var_type="fixed_small", dynamic_threshold=False, clip_denoised=True,
                            rescale_timesteps=True, timestep_respacing="")

@@ -192,3 +192,22 @@ def test_argmin_gather(oracle, golden):
     src = np.arange(4 * 6, dtype=np.float32).reshape(4, 1, 2, 3)
     out = oracle.gather(src, [2, 2, 0])
     np.testing.assert_array_equal(out, src[[2, 2, 0]])
+
+
+# ----------------------------------------------------------------- DDIM step (scope row f2)
+DDIM_CASES = [(999, 0.0), (500, 0.0), (1, 0.0), (0, 0.0), (500, 0.5), (0, 0.5)]
+
+
+@pytest.mark.parametrize("t,eta", DDIM_CASES)
+def test_ddim_step_golden(oracle, golden, t, eta):
+    """oracle DDIM variant of S1 (gaussian_diffusion.py:479-509) against the reference's p_sample and its autograd"""
+    g = golden("ddim")
+    tag = f"t{t}.eta{eta:g}"
+    c = oracle.tables.ddim_step_coefs(oracle.tables.schedule(1000), t, eta)
+    o = oracle.posterior_fwd(g["x"], g[f"{tag}.model_out"], g[f"{tag}.noise"], c)
+    np.testing.assert_array_equal(o["x0_hat"], g[f"{tag}.x0_hat"])
+    assert rel_l2(o["sample"], g[f"{tag}.sample"]) < 1e-6
+    gx, gmo = oracle.posterior_bwd(g["w_x0"], g["w_s"], g["x"], g[f"{tag}.model_out"], g[f"{tag}.noise"], c)
+    assert rel_l2(gx, g[f"{tag}.g_x"]) < 1e-5
+    assert rel_l2(gmo, g[f"{tag}.g_model_out"]) < 1e-5
+    assert np.all(gmo[:, 3:] == 0)          # DDIM ignores the variance channels

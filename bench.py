@@ -172,6 +172,23 @@ def main():
     dur = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) * 1e-3
            for j, k in enumerate(("fwd", "bwd", "upd"))}
 
+    # ---- on-box copy ceiling (report against the vendor peak AND a measured copy kernel):
+    # a 1 GiB device-to-device copy, read + write bytes over its event time
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ce[0].record()
+        for _ in range(5):
+            dst.copy_(src)
+        ce[1].record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 4 / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         total = n * world
         value = total * args.steps / elapsed
@@ -201,7 +218,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n,
                          "avg_launch_ms": dur[dom] * 1e3,
                          "all_launches_ms": {k: v * 1e3 for k, v in dur.items()},
-                         "step_frac_of_hbm_roofline": (17 * P_BYTES * n / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS},
+                         "step_frac_of_hbm_roofline": (17 * P_BYTES * n / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
+                         "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
             "best_of_n_index": best,
         }
         if world == 1 and not args.no_cpu_baseline and args.operator == "gaussian_blur":

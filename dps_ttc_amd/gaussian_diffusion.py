@@ -28,6 +28,7 @@ import torch
 
 from . import kernels
 from .condition_methods import ConditioningMethod
+from .diffstategrad_utils import apply_diffstategrad, compute_svd_and_adaptive_rank
 from .posterior_mean_variance import get_mean_processor, get_var_processor
 
 __SAMPLER__ = {}
@@ -281,8 +282,12 @@ class GaussianDiffusion:
         if self.progress:
             from tqdm.auto import tqdm
             steps = tqdm(list(steps))
+        # DiffStateGrad (reference :203-204, 240-251): off by default; a projected step needs the gradient
+        # itself, so it takes the per-op path; every other step keeps the fused launches
+        period, project = kwargs.get('period', 20), kwargs.get('project', False)
         for idx in steps:
-            if plan is not None:
+            projecting = project and returns_gradient and period != 0 and idx % period == 0
+            if plan is not None and not projecting:
                 noise = self._randn(img)
                 if self.rng_parity:
                     # the reference's q_sample draw (:224), result unused by ps*
@@ -300,7 +305,14 @@ class GaussianDiffusion:
                 if not isinstance(ret, tuple):
                     ret = (ret,)
                 if returns_gradient:
-                    img = kernels.update(out['sample'].detach(), ret[0].detach())     # :255
+                    grad = ret[0].detach()
+                    if projecting:
+                        U, sv, Vh, rank = compute_svd_and_adaptive_rank(z_t=out['sample'].detach(), var_cutoff=0.99)
+                        grad = apply_diffstategrad(norm_grad=grad, iteration_count=idx, period=period, U=U, s=sv,
+                                                   Vh=Vh, adaptive_rank=rank)
+                        if grad.shape[0] != out['sample'].shape[0]:       # [1, C, H, W] broadcasts at :255
+                            grad = grad.expand_as(out['sample']).contiguous()
+                    img = kernels.update(out['sample'].detach(), grad)                # :255
                 else:
                     img = ret[0].detach()
                 distance = ret[1] if len(ret) > 1 else None

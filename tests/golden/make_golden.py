@@ -301,6 +301,7 @@ def main():
     out["resample.ids"] = torch.multinomial(wts, 8, replacement=True).numpy().astype(np.int64)
     save("search.npz", **out)
     ddim_fixtures(GD, CM, MS)
+    project_fixtures(GD, CM, MS)
 
 
 def ddim_fixtures(GD, CM, MS):
@@ -376,14 +377,53 @@ def ddim_fixtures(GD, CM, MS):
     save("ddim.npz", **out)
 
 
+def project_fixtures(GD, CM, MS):
+    """8. base loop with the DiffStateGrad projection (gaussian_diffusion.py:203-204, 240-251) -> project.npz"""
+    out = {}
+    model = StandInModel()
+    noiser = MS.get_noise("gaussian", sigma=0.05)
+    gb = MS.get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device="cpu")
+    for tag, n, period, seed in (("gauss.n1.p5", 1, 5, 80), ("gauss.n2.p4", 2, 4, 81)):
+        with quiet():
+            smp = GD.create_sampler(sampler="ddpm", timestep_respacing="20", **DIFF)
+            cm = CM.get_conditioning_method("ps_semantic", gb, noiser, scale=0.5, sem_guid_scale=0.0)
+        gen = torch.Generator().manual_seed(seed)
+        truth = torch.rand(1, 3, 64, 64, generator=gen) * 2 - 1
+        y = gb.forward(truth)
+        y = y + 0.05 * torch.randn(*y.shape, generator=gen)
+        x_start = torch.randn(n, 3, 64, 64, generator=gen)
+        torch.manual_seed(seed + 1)
+        with quiet() as buf:
+            img, dist, _ = smp.p_sample_loop(model=model, x_start=x_start.clone().requires_grad_(), measurement=y,
+                                             measurement_cond_fn=cm.conditioning, record=False, save_root=None,
+                                             project=True, period=period)
+        out[f"{tag}.y"] = np32(y)
+        out[f"{tag}.x_start"] = np32(x_start)
+        out[f"{tag}.rng_seed"] = np.int64(seed + 1)
+        out[f"{tag}.period"] = np.int64(period)
+        out[f"{tag}.final"] = np32(img)
+        out[f"{tag}.distance"] = np32(dist)
+    # the rank rule alone (diffstategrad_utils.py:4-44) on a fixed state
+    from guided_diffusion.diffstategrad_utils import compute_svd_and_adaptive_rank
+    gen = torch.Generator().manual_seed(82)
+    z = torch.randn(2, 3, 64, 64, generator=gen) * torch.linspace(2.0, 0.05, 64).view(1, 1, 1, 64)
+    for cutoff in (0.99, 0.9, 0.5):
+        out[f"rank.cut{cutoff:g}"] = np.int64(compute_svd_and_adaptive_rank(z, cutoff)[3])
+    out["rank.z"] = np32(z)
+    save("project.npz", **out)
+
+
 if __name__ == "__main__":
-    if "--only-ddim" in sys.argv:       # adds ddim.npz without rewriting the other fixtures
+    extra = {"--only-ddim": ddim_fixtures, "--only-project": project_fixtures}
+    chosen = [fn for flag, fn in extra.items() if flag in sys.argv]
+    if chosen:                          # add fixtures without rewriting the others
         install_stubs()
         with quiet():
             from guided_diffusion import condition_methods as CM
             from guided_diffusion import gaussian_diffusion as GD
             from guided_diffusion import measurements as MS
         torch.set_num_threads(8)
-        ddim_fixtures(GD, CM, MS)
+        for fn in chosen:
+            fn(GD, CM, MS)
     else:
         main()

@@ -483,6 +483,24 @@ def test_ttc_ddim_fused_matches_per_op(K, golden):
     assert rel_l2(res[0][0], res[1][0]) < 1e-5 and rel_l2(res[0][1], res[1][1]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["gauss.n1.p5", "gauss.n2.p4"])
+def test_base_loop_diffstategrad_golden(K, golden, tag):
+    """base loop with project=True (reference gaussian_diffusion.py:203-204, 240-251): fused launches on ordinary
+    steps, per-op path + rocSOLVER SVD projection every `period` steps; final image within the 1e-4 gate"""
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.measurements import get_noise
+    g = golden("project")
+    op, _ = make_product_op("gauss", hw=64)
+    cm = get_conditioning_method("ps_semantic", op, get_noise("gaussian", sigma=0.05), scale=0.5, sem_guid_scale=0.0)
+    smp = _sampler("ddpm", "20")
+    torch.manual_seed(int(g[f"{tag}.rng_seed"]))
+    img, dist, _ = smp.p_sample_loop(model=StandInModel().to(DEV), x_start=dev(g[f"{tag}.x_start"]).requires_grad_(),
+                                     measurement=dev(g[f"{tag}.y"]), measurement_cond_fn=cm.conditioning, record=False,
+                                     save_root=None, project=True, period=int(g[f"{tag}.period"]))
+    assert rel_l2(host(img), g[f"{tag}.final"]) < 1e-4
+    assert rel_l2(host(dist), g[f"{tag}.distance"]) < 1e-4
+
+
 @pytest.mark.parametrize("tag,oname", [("sr4", "sr4"), ("gauss", "gauss")])
 def test_search_ddpm_golden(K, golden, tag, oname):
     """per-step best-of-N: winner indices bit-exact, costs and final image within 1e-5 / 1e-4"""

@@ -155,3 +155,23 @@ def test_space_timesteps_and_schedules():
         get_named_beta_schedule("no_such_schedule", 10)
     cos = get_named_beta_schedule("cosine", 100)
     assert cos.shape == (100,) and 0 < cos.min() and cos.max() <= 0.999
+
+
+def test_diffstategrad_rank_rule_and_projection(golden):
+    """reference diffstategrad_utils.py:4-78: the (flattened-cumsum) rank rule against values captured from the
+    reference, and the projector's algebra (idempotent, identity off-period)"""
+    from dps_ttc_amd.diffstategrad_utils import apply_diffstategrad, compute_svd_and_adaptive_rank
+    g = golden("project")
+    z = torch.from_numpy(g["rank.z"])
+    for cutoff in (0.99, 0.9, 0.5):
+        U, s, Vh, rank = compute_svd_and_adaptive_rank(z, cutoff)
+        assert rank == int(g[f"rank.cut{cutoff:g}"])
+    grad = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    assert apply_diffstategrad(grad, 7, 5, U, s, Vh, rank) is grad                 # off-period: untouched
+    assert apply_diffstategrad(grad, 10, 0, U, s, Vh, rank) is grad                # period 0: never
+    p1 = apply_diffstategrad(grad, 10, 5, U, s, Vh, rank)
+    assert p1.shape == (1, 3, 64, 64)                                              # batch-0 only, as the reference
+    p2 = apply_diffstategrad(p1, 10, 5, U, s, Vh, rank)
+    assert float((p1 - p2).norm() / p1.norm()) < 1e-5
+    with pytest.raises(ValueError):
+        apply_diffstategrad(grad, 10, 5)

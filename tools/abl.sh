@@ -1,5 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 -m pytest tests -x -q -m gpu 2>&1 | tail -8
-python3 bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
-cat gpurun_out/bench_n1.json
+python3 -m pytest tests/test_hip_parity.py -x -q -m gpu -k "persistent or fused_step" 2>&1 | tail -5
+for d in 0 256 0 256; do
+  echo "== DBG $d"
+  DPSX_DBG=$d python3 tools/kbench.py --only bwd --reps 40 2>&1 | grep -E "fwd|bwd|upd"
+done

@@ -70,12 +70,16 @@ __device__ __forceinline__ float norm_coef_r(float nv, float gn, int power)
     return power == 2 ? -2.0f * gn : (nv == 0.0f ? 0.0f : -gn / nv);
 }
 
-// LDS: s_in[fwd_rows][in_w] | s_tmp[fwd_rows][out_w] | s_red[8]
+// LDS: s_in[fwd_rows][iws] | s_tmp[fwd_rows][out_w] | s_red[8]
+// A staged row is stored RESIDUE-MAJOR: column j sits at word (j % 4) * q4 + j / 4 (q4 = ceil(in_w / 4), iws = 4 q4).
+// The W pass reads column ~(in_w / out_w) * o + const in lane o: in plain order that is a stride of 4 words for x4
+// (8-way bank conflict, 20 us of the 84 us launch at N = 64); residue-major, consecutive lanes read consecutive words.
 template <bool POST, bool RESID, bool VEC>
 __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
 {
     extern __shared__ __align__(16) float lds[];
-    float *s_in = lds, *s_tmp = lds + d.fwd_rows * d.in_w, *s_red = s_tmp + d.fwd_rows * d.out_w;
+    const int q4 = (d.in_w + 3) / 4, iws = 4 * q4;
+    float *s_in = lds, *s_tmp = lds + d.fwd_rows * iws, *s_red = s_tmp + d.fwd_rows * d.out_w;
     const int nblk = (d.out_h + d.tp - 1) / d.tp;
     const int plane = blockIdx.x / nblk, blk = blockIdx.x % nblk;
     const int lo = d.blk_lo[blk], cnt = d.blk_cnt[blk];
@@ -86,7 +90,8 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     int *s_iw = reinterpret_cast<int *>(s_wh + d.taps_h * d.tp), *s_ih = s_iw + d.taps_w * d.out_w;
     for (int i = threadIdx.x; i < d.taps_w * d.out_w; i += RT) {
         s_ww[i] = d.w_w[i];
-        s_iw[i] = d.i_w[i];
+        const int j = d.i_w[i];
+        s_iw[i] = (j & 3) * q4 + (j >> 2);
     }
     const int p0 = blk * d.tp, p1 = min(d.out_h, p0 + d.tp);
     for (int i = threadIdx.x; i < d.taps_h * d.tp; i += RT) {
@@ -172,9 +177,13 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
                         }
                     }
                 }
-                float *dst = s_in + rr * d.in_w + gx;
-                if constexpr (VEC) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
-                else dst[0] = val[0];
+                float *dst = s_in + rr * iws;
+                if constexpr (VEC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e * q4 + cu] = val[e];      // gx = 4 cu: residue e, quotient cu
+                } else {
+                    dst[(gx & 3) * q4 + (gx >> 2)] = val[0];
+                }
             }
         }
     }
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     // ---- stage B: W pass  tmp[r][o] = sum_k w_w[k,o] * in[r][i_w[k,o]]
     for (int it = threadIdx.x; it < cnt * d.out_w; it += RT) {
         const int rr = it / d.out_w, o = it - rr * d.out_w;
-        const float *row = s_in + rr * d.in_w;
+        const float *row = s_in + rr * iws;
         float acc = 0.0f;
         for (int k = 0; k < d.taps_w; ++k)
             acc = fmaf(s_ww[k * d.out_w + o], row[s_iw[k * d.out_w + o]], acc);
@@ -197,6 +206,157 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
         for (int k = 0; k < d.taps_h; ++k)
             acc = fmaf(s_wh[k * d.tp + pl], s_tmp[s_ih[k * d.tp + pl] * d.out_w + o], acc);
         const int64_t oo = (int64_t)p * d.out_w + o;
+        if constexpr (RESID) {
+            const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
+            const float r = yv - acc;
+            if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
+            ss = fmaf(r, r, ss);
+        } else {
+            a.out[(int64_t)plane * ohw + oo] = acc;
+        }
+    }
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row-streaming forward (the common geometries: in_w = 4 wu with wu | 64, out_w <= wu i.e. scale >= 4, <= 32 taps).
+// One wave-instruction loads 64 float4 units = 64 / wu WHOLE rows, so the W pass of those rows runs right away out
+// of a 1 KiB per-wave row buffer and only its result (out_w floats per row) is kept for the H pass: LDS per block
+// drops from fwd_rows * (in_w + out_w) floats (65 KB at 256 -> 64, two blocks per CU) to ~17 KB, lane q owns one
+// W output column for the whole block so its taps and (residue-major) indices live in registers, and the blocks
+// of a plane share an XCD so the input rows neighbouring bands both stage are L2 hits.
+// LDS: s_buf[4 waves][256] | s_tmp[fwd_rows][out_w] | s_red[16] | s_wh[taps_h][tp] | s_ih[taps_h][tp]
+__device__ float g_zero_unit_rz[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // never written; non-const keeps it global-space
+
+template <bool POST, bool RESID, int TWN, int B>
+__global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeDev d)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int wu = d.in_w >> 2, rps = 64 / wu, iws = d.in_w;
+    const int nblk = (d.out_h + d.tp - 1) / d.tp;
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int plane = (kq / nblk) * 8 + xcd, blk = kq % nblk;
+    if (plane >= a.planes) return;
+    float *s_buf = lds, *s_tmp = lds + 4 * 256, *s_red = s_tmp + d.fwd_rows * d.out_w, *s_wh = s_red + 16;
+    int *s_ih = reinterpret_cast<int *>(s_wh + d.taps_h * d.tp);
+    const int lo = d.blk_lo[blk], cnt = d.blk_cnt[blk];
+    const unsigned ihw = (unsigned)(d.in_h * d.in_w), ohw = (unsigned)(d.out_h * d.out_w);
+    const int n = plane / a.c, ch = plane % a.c;
+    const int p0 = blk * d.tp, p1 = min(d.out_h, p0 + d.tp);
+    for (int i = threadIdx.x; i < d.taps_h * d.tp; i += RT) {
+        const int k = i / d.tp, p = p0 + i % d.tp;
+        s_wh[i] = p < d.out_h ? d.w_h[k * d.out_h + p] : 0.0f;
+        s_ih[i] = p < d.out_h ? d.i_h[k * d.out_h + p] - lo : 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- this lane's W output: row rq of the wave-step, column oq; taps and remapped indices in registers
+    const int nq = rps * d.out_w;
+    const int rq = lane / d.out_w, oq = lane - rq * d.out_w;
+    float ww[TWN];
+    int iw[TWN];
+    {   // unconditional loads from clamped addresses, all issued before the first is used (a load under a divergent
+        // branch, or one the next address depends on, costs a serialised round trip each); lanes without an output
+        // and taps beyond taps_w get weight 0 and a valid index
+        const bool has_out = lane < nq;
+        const int rqc = has_out ? rq : 0, oqc = has_out ? oq : 0;
+        int jj[TWN];
+#pragma unroll
+        for (int k = 0; k < TWN; ++k) {
+            const int kk = min(k, d.taps_w - 1);
+            ww[k] = d.w_w[kk * d.out_w + oqc];
+            jj[k] = d.i_w[kk * d.out_w + oqc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < TWN; ++k) {
+            ww[k] = (has_out && k < d.taps_w) ? ww[k] : 0.0f;
+            iw[k] = rqc * iws + (jj[k] & 3) * wu + (jj[k] >> 2);
+        }
+    }
+    const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+    int olo = 0, ohi = 0;
+    if constexpr (POST) {
+        src = a.x_t + (int64_t)plane * ihw;
+        eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * ihw;
+        vv = eps + (int64_t)a.c * ihw;
+        zz = a.noise + (int64_t)plane * ihw;
+        olo = d.own_lo[blk];
+        ohi = d.own_lo[blk + 1];
+    } else {
+        src = a.x + (int64_t)plane * ihw;
+    }
+    float *mybuf = s_buf + wave * 256;
+    const int rl = lane / wu, cu = lane - rl * wu;
+    const int nsteps = (cnt + rps - 1) / rps;
+    const bool noisy = POST && (a.k.add_noise & 1);
+    for (int s0 = wave; s0 < nsteps; s0 += 4 * B) {
+        float4 xv[B], ev[B], vq[B], zq[B];
+#pragma unroll
+        for (int bb = 0; bb < B; ++bb) {
+            const int rr = min((s0 + 4 * bb) * rps + rl, cnt - 1);      // surplus lanes / steps re-read the last row
+            const int gy = lo + rr;
+            const unsigned o = (unsigned)(gy * d.in_w + 4 * cu);
+            xv[bb] = *reinterpret_cast<const float4 *>(src + o);
+            if constexpr (POST) {
+                ev[bb] = *reinterpret_cast<const float4 *>(eps + o);
+                // rows this block does not own read a block of zeros: the loads themselves stay unconditional
+                const bool own = noisy && gy >= olo && gy < ohi;
+                vq[bb] = *reinterpret_cast<const float4 *>(own ? vv + o : g_zero_unit_rz);
+                zq[bb] = *reinterpret_cast<const float4 *>(own ? zz + o : g_zero_unit_rz);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bb = 0; bb < B; ++bb) {
+            const int st = s0 + 4 * bb;
+            if (st >= nsteps) break;                                     // wave-uniform
+            const int rr = st * rps + rl;
+            const int gy = lo + rr;
+            float val[4] = {xv[bb].x, xv[bb].y, xv[bb].z, xv[bb].w};
+            if constexpr (POST) {
+                bool ins[4];
+                val[0] = post_x0(xv[bb].x, ev[bb].x, a.k, ins[0]);
+                val[1] = post_x0(xv[bb].y, ev[bb].y, a.k, ins[1]);
+                val[2] = post_x0(xv[bb].z, ev[bb].z, a.k, ins[2]);
+                val[3] = post_x0(xv[bb].w, ev[bb].w, a.k, ins[3]);
+                if (rr < cnt && gy >= olo && gy < ohi) {
+                    float4 sm;
+                    sm.x = post_sample(xv[bb].x, val[0], vq[bb].x, zq[bb].x, a.k);
+                    sm.y = post_sample(xv[bb].y, val[1], vq[bb].y, zq[bb].y, a.k);
+                    sm.z = post_sample(xv[bb].z, val[2], vq[bb].z, zq[bb].z, a.k);
+                    sm.w = post_sample(xv[bb].w, val[3], vq[bb].w, zq[bb].w, a.k);
+                    const int64_t po = (int64_t)plane * ihw + (unsigned)(gy * d.in_w + 4 * cu);
+                    *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                    *reinterpret_cast<float4 *>(a.sample + po) = sm;
+                    *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
+                }
+            }
+            // residue-major rows of this step -> the wave's buffer; DS operations of one wave execute in order, so the
+            // gathers below see these writes and the next step's writes cannot pass this step's reads
+            float *dst = mybuf + rl * iws + cu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * wu] = val[e];
+            if (lane < nq && st * rps + rq < cnt) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < TWN; ++k)
+                    if (k < d.taps_w) acc = fmaf(ww[k], mybuf[iw[k]], acc);
+                s_tmp[(st * rps + rq) * d.out_w + oq] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- H pass  out[p][o] = sum_k w_h[k,p] * tmp[i_h[k,p] - lo][o]   (as in k_resize_fwd)
+    float ss = 0.0f;
+    for (int it = threadIdx.x; it < (p1 - p0) * d.out_w; it += RT) {
+        const int pl = it / d.out_w, p = p0 + pl, o = it % d.out_w;
+        float acc = 0.0f;
+        for (int k = 0; k < d.taps_h; ++k)
+            acc = fmaf(s_wh[k * d.tp + pl], s_tmp[s_ih[k * d.tp + pl] * d.out_w + o], acc);
+        const unsigned oo = (unsigned)(p * d.out_w + o);
         if constexpr (RESID) {
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
             const float r = yv - acc;
@@ -229,9 +389,27 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     const float *up = a.x + (int64_t)plane * ohw + (int64_t)lo * d.out_w;
     for (int u = threadIdx.x; u < cnt * d.out_w; u += RT) s_u[u] = up[u];
     // inverse tables -> LDS: the whole W inverse, and the H-inverse rows of this block (rebased to 0)
-    for (int i = threadIdx.x; i < elln; i += RT) {      // [ell_w][in_w]: lane j reads word k*in_w + j, conflict-free
-        s_wi[i] = d.ell_w_idx[i];
-        s_wv[i] = d.ell_w_w[i];
+    // RT % (in_w / 4) == 0: a lane keeps its column group over all its rows, so the (<= 8 deep) ELL entries of its
+    // four columns go from global memory (16-byte loads, L2-resident) straight to registers, once; otherwise the W
+    // inverse is staged in LDS and read per element
+    constexpr int EW = 8;
+    const bool regtab = VEC && RT % (d.in_w / 4) == 0 && d.ell_w <= EW;
+    float4 tw[EW];
+    int4 ti4[EW];
+    if (regtab) {
+        const int j0 = (threadIdx.x % (d.in_w / 4)) * 4;
+#pragma unroll
+        for (int k = 0; k < EW; ++k) {
+            const int kk = min(k, d.ell_w - 1);
+            tw[k] = *reinterpret_cast<const float4 *>(d.ell_w_w + kk * d.in_w + j0);
+            ti4[k] = *reinterpret_cast<const int4 *>(d.ell_w_idx + kk * d.in_w + j0);
+            if (k >= d.ell_w) tw[k] = make_float4(0, 0, 0, 0);          // weight 0, any valid index
+        }
+    } else {
+        for (int i = threadIdx.x; i < elln; i += RT) {      // [ell_w][in_w]: lane j reads word k*in_w + j, conflict-free
+            s_wi[i] = d.ell_w_idx[i];
+            s_wv[i] = d.ell_w_w[i];
+        }
     }
     const int he0 = d.inv_h_ptr[i0], he1 = d.inv_h_ptr[i1];
     for (int i = threadIdx.x; i <= i1 - i0; i += RT) s_hp[i] = d.inv_h_ptr[i0 + i] - he0;
@@ -264,12 +442,27 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     for (int it = threadIdx.x; it < (i1 - i0) * wu; it += RT) {
         const int ii = it / wu, j0 = (it - ii * wu) * U;
         float g[U];
+        if (VEC && regtab) {
+            if constexpr (VEC) {
+                const float *trow = s_t + ii * d.out_w;
+                g[0] = g[1] = g[2] = g[3] = 0.0f;
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-            float acc = 0.0f;
-            for (int k = 0; k < d.ell_w; ++k)
-                acc = fmaf(s_wv[k * d.in_w + j0 + q], s_t[ii * d.out_w + s_wi[k * d.in_w + j0 + q]], acc);
-            g[q] = acc;
+                for (int k = 0; k < EW; ++k)
+                    if (k < d.ell_w) {          // same entry order as the LDS form: bit-identical sums
+                        g[0] = fmaf(tw[k].x, trow[ti4[k].x], g[0]);
+                        g[1] = fmaf(tw[k].y, trow[ti4[k].y], g[1]);
+                        g[2] = fmaf(tw[k].z, trow[ti4[k].z], g[2]);
+                        g[3] = fmaf(tw[k].w, trow[ti4[k].w], g[3]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                float acc = 0.0f;
+                for (int k = 0; k < d.ell_w; ++k)
+                    acc = fmaf(s_wv[k * d.in_w + j0 + q], s_t[ii * d.out_w + s_wi[k * d.in_w + j0 + q]], acc);
+                g[q] = acc;
+            }
         }
         const int64_t o = (int64_t)(i0 + ii) * d.in_w + j0;
         if constexpr (EPI) {
@@ -398,7 +591,7 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
             cnt[(size_t)b] = mx - mn + 1;
             maxrows = std::max(maxrows, mx - mn + 1);
         }
-        const size_t lds = ((size_t)maxrows * (d.in_w + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * tp)) * 4;
+        const size_t lds = ((size_t)maxrows * ((d.in_w + 3) / 4 * 4 + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * tp)) * 4;
         if (lds <= kLdsBudget || tp == 1) {
             best_tp = tp; d.fwd_rows = maxrows; blo = lo; bcnt = cnt; own = ow_;
             if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
@@ -485,7 +678,15 @@ static int launch_fwd(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
 {
     const ResizeDev &d = dev_of(op);
     const unsigned grid = (unsigned)(a.planes * ((d.out_h + d.tp - 1) / d.tp));
-    const size_t lds = ((size_t)d.fwd_rows * (d.in_w + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * d.tp)) * 4;
+    const size_t lds = ((size_t)d.fwd_rows * ((d.in_w + 3) / 4 * 4 + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * d.tp)) * 4;
+    const int wu = d.in_w / 4;
+    static const bool no_rows = getenv("DPSX_RESIZE_NO_ROWS") != nullptr;        // A/B switch for tools/kbench.py
+    if (vec && !no_rows && d.in_w % 4 == 0 && wu >= 1 && wu <= 64 && 64 % wu == 0 && d.out_w <= wu && d.taps_w <= 32) {
+        const unsigned grid_x = (unsigned)((a.planes + 7) / 8 * 8 * ((d.out_h + d.tp - 1) / d.tp));
+        const size_t lds_r = ((size_t)4 * 256 + (size_t)d.fwd_rows * d.out_w + 16 + 2 * (size_t)(d.taps_h * d.tp)) * 4;
+        if (d.taps_w <= 16) RZ_LAUNCH((k_resize_fwd_rows<POST, RESID, 16, 4>), grid_x, lds_r, s, a, d);
+        RZ_LAUNCH((k_resize_fwd_rows<POST, RESID, 32, 2>), grid_x, lds_r, s, a, d);
+    }
     if (vec) RZ_LAUNCH((k_resize_fwd<POST, RESID, true>), grid, lds, s, a, d);
     RZ_LAUNCH((k_resize_fwd<POST, RESID, false>), grid, lds, s, a, d);
 }

@@ -134,6 +134,38 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
         op->nnz = (int)w.size();
         int rc = upload_taps(op, dy, dx, w);
         if (rc != DPSX_OK) { dpsx_op_destroy(op); return rc; }
+        // vertical runs of <= 4 taps per kernel column, window kept inside [-reach4, reach4]
+        std::vector<TapRun> fwd, adj;
+        for (int j = 0; j < ks; ++j) {
+            int i = 0;
+            while (i < ks) {
+                if (kernel_host[i * ks + j] == 0.0f) { ++i; continue; }
+                const int first = i - R;                               // dy of the run's first tap
+                const int dy0 = std::min(first, reach4 - 3);           // shift up so dy0 + 3 <= reach4
+                TapRun r{};
+                r.dy0 = dy0; r.dx = j - R;
+                for (int q = 0; q < 4; ++q) {
+                    const int ii = dy0 + q + R;
+                    r.w[q] = (ii >= 0 && ii < ks && ii >= i) ? kernel_host[ii * ks + j] : 0.0f;
+                }
+                fwd.push_back(r);
+                // adjoint (correlation-transpose): V[p][q] = sum w_t u[p - dy_t][q - dx_t] -> negated offsets,
+                // reversed weights, same loop
+                TapRun t{};
+                t.dy0 = -(dy0 + 3); t.dx = -(j - R);
+                for (int q = 0; q < 4; ++q) t.w[q] = r.w[3 - q];
+                adj.push_back(t);
+                i = dy0 + 4 + R;                                       // first row not covered by this run
+            }
+        }
+        op->nruns = (int)fwd.size();
+        const size_t bytes = std::max<size_t>(fwd.size(), 1) * sizeof(TapRun);
+        if (hipMalloc(&op->d_runs_fwd, bytes) != hipSuccess || hipMalloc(&op->d_runs_adj, bytes) != hipSuccess ||
+            (!fwd.empty() && (hipMemcpy(op->d_runs_fwd, fwd.data(), fwd.size() * sizeof(TapRun), hipMemcpyHostToDevice) != hipSuccess ||
+                              hipMemcpy(op->d_runs_adj, adj.data(), adj.size() * sizeof(TapRun), hipMemcpyHostToDevice) != hipSuccess))) {
+            dpsx_op_destroy(op);
+            return DPSX_ENOMEM;
+        }
     }
     *out = op;
     return DPSX_OK;
@@ -197,6 +229,8 @@ void dpsx_op_destroy(dpsx_op *op)
     if (op->d_tap_dy) (void)hipFree(op->d_tap_dy);
     if (op->d_tap_dx) (void)hipFree(op->d_tap_dx);
     if (op->d_tap_w) (void)hipFree(op->d_tap_w);
+    if (op->d_runs_fwd) (void)hipFree(op->d_runs_fwd);
+    if (op->d_runs_adj) (void)hipFree(op->d_runs_adj);
     if (op->kind == OP_RESIZE) resize_destroy(op);
     if (op->kind == OP_PHASE) phase_destroy(op);
     delete op;

@@ -49,9 +49,8 @@ struct BlurArgs {
     int c, h, w, tiles_x, tiles_y, planes;
     Coefs k;
     // generic taps
-    const int *tap_dy, *tap_dx;
-    const float *tap_w;
-    int nnz;
+    const TapRun *runs;   // vertical runs of <= 4 taps (forward table, or the adjoint's negated / reversed one)
+    int nruns;
     int dbg;   // diagnostic phase mask (env DPSX_DBG), 0 in production
     // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
     // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
@@ -254,7 +253,39 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
 // consecutive lanes read consecutive LDS words (conflict-free ds_read_b32).
 // LDS: s_in[RH][SW] | 256 floats of scratch
 // =====================================================================
-constexpr int GI = 16;  // outputs per thread
+constexpr int GI = 16;  // outputs per thread: GI consecutive rows of one column
+
+// acc[i] = sum over the runs of sum_j w[j] * base[(i + dy0 + j) * SW + dx]: the GI + 3 inputs of a run are read once
+// (consecutive lanes -> consecutive LDS words), the run record through wave-uniform scalar loads
+// SWC > 0: the LDS row stride is a compile-time constant, so the GI + 3 reads of a run are one base register plus
+// immediate offsets; SWC == 0: runtime stride.  The next run's record is fetched while this one is processed.
+template <int SWC>
+__device__ __forceinline__ void tap_runs(float (&acc)[GI], const float *base, const int sw_rt, const TapRun *runs,
+                                         const int nruns)
+{
+    const int SW = SWC > 0 ? SWC : sw_rt;
+#pragma unroll
+    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
+    if (nruns <= 0) return;
+    TapRun r = runs[0];
+    for (int t = 0; t < nruns; ++t) {
+        const TapRun nxt = runs[min(t + 1, nruns - 1)];
+        const float *p = base + r.dy0 * SW + r.dx;
+        float win[GI + 3];
+#pragma unroll
+        for (int m = 0; m < GI + 3; ++m) win[m] = p[m * SW];
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            acc[i] = fmaf(r.w[0], win[i], acc[i]);
+            acc[i] = fmaf(r.w[1], win[i + 1], acc[i]);
+            acc[i] = fmaf(r.w[2], win[i + 2], acc[i]);
+            acc[i] = fmaf(r.w[3], win[i + 3], acc[i]);
+        }
+        r = nxt;
+    }
+}
+
+constexpr int kTapsSwFull = TW + 2 * kMaxRadius + 4;   // row stride of the RR = 32 image (61 x 61 kernels)
 
 template <bool POST, bool RESID, bool VEC>
 __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
@@ -267,23 +298,16 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
     const int h0 = ty * TH, w0 = tx * TW;
     load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
     __syncthreads();
-    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
     float acc[GI];
-#pragma unroll
-    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
-    const float *base = s_in + (r0 + RR) * SW + col + RR;
-    for (int t = 0; t < a.nnz; ++t) {
-        const float wgt = a.tap_w[t];
-        const float *p = base + a.tap_dy[t] * SW + a.tap_dx[t];
-#pragma unroll
-        for (int i = 0; i < GI; ++i) acc[i] = fmaf(wgt, p[4 * i * SW], acc[i]);
-    }
+    if (RR == kMaxRadius) tap_runs<kTapsSwFull>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
+    else tap_runs<0>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
     const int ox = w0 + col;
     float ss = 0.0f;
     if (ox < a.w) {
 #pragma unroll
         for (int i = 0; i < GI; ++i) {
-            const int oy = h0 + r0 + 4 * i;
+            const int oy = h0 + r0 + i;
             if constexpr (RESID) ss += resid_epilogue<false>(a, plane, oy, ox, &acc[i], 1);
             else out_epilogue<false>(a, plane, oy, ox, &acc[i], 0.0f, false, 1);
         }
@@ -311,21 +335,14 @@ __global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, int RR)
     const int h0 = ty * TH, w0 = tx * TW;
     load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
     __syncthreads();
-    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
     float acc[GI];
-#pragma unroll
-    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
-    const float *base = s_in + (r0 + RR) * SW + col + RR;
-    for (int t = 0; t < a.nnz; ++t) {
-        const float wgt = a.tap_w[t];
-        const float *p = base - a.tap_dy[t] * SW - a.tap_dx[t];
-#pragma unroll
-        for (int i = 0; i < GI; ++i) acc[i] = fmaf(wgt, p[4 * i * SW], acc[i]);
-    }
+    if (RR == kMaxRadius) tap_runs<kTapsSwFull>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
+    else tap_runs<0>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);       // a.runs: the adjoint table
     const int ox = w0 + col;
     if (ox < a.w) {
 #pragma unroll
-        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + 4 * i, ox, &acc[i], 0.0f, false, 1);
+        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + i, ox, &acc[i], 0.0f, false, 1);
     }
 }
 
@@ -480,7 +497,7 @@ static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 
 static void set_taps(const dpsx_op *op, BlurArgs &a)
 {
-    a.tap_dy = op->d_tap_dy; a.tap_dx = op->d_tap_dx; a.tap_w = op->d_tap_w; a.nnz = op->nnz;
+    a.runs = static_cast<const TapRun *>(op->d_runs_fwd); a.nruns = op->nruns;
 }
 
 template <bool POST, bool RESID>
@@ -512,7 +529,7 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     c.x = a.x; c.out = scratch;
     fill_geometry(c, a.planes, 1, ph, pw);
     c.src_h = a.h; c.src_w = a.w; c.src_off = r4;
-    set_taps(op, c);
+    c.runs = static_cast<const TapRun *>(op->d_runs_adj); c.nruns = op->nruns;
     const size_t lds = taps_lds_bytes(r4);
     const bool v2 = vec && aligned16(scratch);
     {

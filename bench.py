@@ -77,6 +77,10 @@ def build_operator(name, device):
         return get_operator("motion_blur", kernel_size=61, intensity=0.5, device=device), {}
     if name == "super_resolution":
         return get_operator("super_resolution", in_shape=(1, 3, 256, 256), scale_factor=4, device=device), {}
+    if name == "phase_retrieval":
+        return get_operator("phase_retrieval", oversample=2.0, device=device), {}
+    if name != "inpainting":
+        raise SystemExit(f"unknown operator {name}")
     g = torch.Generator().manual_seed(7)
     mask = (torch.rand((1, 1, 256, 256), generator=g) < 0.5).float().to(device)
     return get_operator("inpainting", device=device), {"mask": mask}

@@ -61,6 +61,8 @@ SIGNATURES = {
                                   _i64, _i64, _i64, _i64, POINTER(Coefs), _p, _i64, _p]),
     "dpsx_step_bwd_f32": (c_int, [c_void_p, _p, _f, _f, _p, _f, _f, _i64, c_float, c_int, _f,
                                   _i64, _i64, _i64, _i64, POINTER(Coefs), _p, _i64, _p]),
+    "dpsx_step_bwd_extra_f32": (c_int, [c_void_p, _p, _f, _f, _p, _f, _f, _i64, c_float, c_int, _f, _f,
+                                        _i64, _i64, _i64, _i64, POINTER(Coefs), _p, _i64, _p]),
     "dpsx_step_update_f32": (c_int, [_f, _f, _f, _f, _i64, _i64, POINTER(Coefs), _p]),
     "dpsx_update_f32": (c_int, [_f, _f, _f, _f, _i64, _p]),
     "dpsx_score_f32": (c_int, [c_void_p, _f, _f, _i64, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),

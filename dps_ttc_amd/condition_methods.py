@@ -11,6 +11,7 @@ operator.forward (OperatorFn), `torch.autograd.grad` walks:  UNet  <-  [HIP S1 V
 <-  [HIP A^T]  <-  [HIP norm VJP].  The samplers in gaussian_diffusion.py bypass
 this per-op chain with the three fused launches when `fused_spec()` allows it.
 """
+import functools
 import math
 from abc import ABC, abstractmethod
 
@@ -164,10 +165,26 @@ class PosteriorSamplingSemanticGuid(ConditioningMethod):
         return self.sem_guid_scale * (1 + (self.anneal_factor - 1) / (1 + math.exp(-10 * (0.3 - t))))
 
     def fused_spec(self, **kwargs):
-        if self.noiser.__name__ != 'gaussian' or self.sem_guid_scale != 0:
+        if self.noiser.__name__ != 'gaussian':
             return None
         # the measurement term is first-power whatever norm_exp says (:177-184)
-        return {"scale": float(self.scale), "power": 1}
+        spec = {"scale": float(self.scale), "power": 1}
+        if self.sem_guid_scale != 0:
+            # the semantic term depends on x0_hat only: its cotangent on x0_hat joins coef * A^T r in the fused
+            # backward launch (dpsx_step_bwd_extra_f32), the embedder and its VJP stay torch
+            spec["semantic"] = functools.partial(self.semantic_cotangent, t=kwargs.get('t', 1))
+        return spec
+
+    def semantic_cotangent(self, x_0_hat, t=1):
+        """-> (d [sem_guid_scale_t * semantic_loss.sum()] / d x0_hat, sem_guid_norm[N])   (:150-175)"""
+        x = x_0_hat.detach().requires_grad_()
+        with torch.enable_grad():
+            emb = self.embedder(x).unsqueeze(1)
+            sem_diff = (emb - self.guid_image_emb).reshape(emb.shape[0], -1)
+            sem_guid_norm = torch.norm(sem_diff, dim=-1) / self.n_guid_images
+            semantic_loss = sem_guid_norm ** 2 if self.norm_exp == 2 else sem_guid_norm
+            (g,) = torch.autograd.grad((self.semantic_scale(t) * semantic_loss).sum(), x)
+        return g, sem_guid_norm.detach()
 
     def measurement_semantic_guidance(self, x_prev, x_0_hat, measurement, **kwargs):
         if self.sem_guid_scale == 0:

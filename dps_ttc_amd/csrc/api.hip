@@ -493,6 +493,16 @@ int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *
                       float *g_model_out, int64_t n, int64_t c, int64_t h, int64_t w,
                       const dpsx_coefs *coefs_host, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    return dpsx_step_bwd_extra_f32(op, resid, norm, norm_out, inside, x0_hat, y, y_n, scale, power, nullptr,
+                                   g_model_out, n, c, h, w, coefs_host, workspace, workspace_bytes, stream);
+}
+
+int dpsx_step_bwd_extra_f32(dpsx_op *op, const void *resid, const float *norm, float *norm_out,
+                            const uint8_t *inside, const float *x0_hat, const float *y, int64_t y_n, float scale,
+                            int power, const float *g_x0_extra, float *g_model_out, int64_t n, int64_t c, int64_t h,
+                            int64_t w, const dpsx_coefs *coefs_host, void *workspace, int64_t workspace_bytes,
+                            void *stream)
+{
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
     if (!resid || !inside || !g_model_out || !coefs_host || (power != 1 && power != 2)) return DPSX_EINVAL;
@@ -512,7 +522,7 @@ int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *
         }
     }
     StepBwdArgs b{static_cast<const float *>(resid), norm, ws.partials, parts, norm_out, inside, x0_hat, y, y_n,
-                  scale, power, g_model_out, n, c, h, w, k};
+                  scale, power, g_model_out, n, c, h, w, k, g_x0_extra};
     switch (op->kind) {
     case OP_SEP:
     case OP_TAPS: return blur_step_bwd(op, b, static_cast<float *>(ws.priv), ws.priv_bytes, s);
@@ -524,11 +534,11 @@ int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *
         return mask_step_bwd(op, b, s);
     case OP_IDENT:
         return clamp_scale_to_eps(static_cast<const float *>(resid), norm, inside, scale, power, g_model_out, n,
-                                  chw, k, s);
+                                  chw, k, s, g_x0_extra);
     case OP_PHASE:
         rc = phase_step_bwd(op, const_cast<float *>(static_cast<const float *>(resid)), ws.img, n * c, s);
         if (rc != DPSX_OK) return rc;
-        return clamp_scale_to_eps(ws.img, norm, inside, scale, power, g_model_out, n, chw, k, s);
+        return clamp_scale_to_eps(ws.img, norm, inside, scale, power, g_model_out, n, chw, k, s, g_x0_extra);
     }
     return DPSX_EUNSUPPORTED;
 }

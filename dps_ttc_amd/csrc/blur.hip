@@ -42,6 +42,7 @@ struct BlurArgs {
     int norm_parts;
     float *norm_out;
     const uint8_t *inside_r;
+    const float *g_extra;  // optional extra cotangent on x0_hat, added before the clamp gate (nullable)
     float *g_model_out;
     float scale;
     int power;
@@ -231,17 +232,20 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
     const uint8_t *ip = a.inside_r + (int64_t)plane * hw + o;
     float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
     const float mb = -a.k.b;
+    const float *ep = a.g_extra ? a.g_extra + (int64_t)plane * hw + o : nullptr;
     if (VEC4 && count == 4 && ox + 3 < a.w) {
         const uchar4 in = *reinterpret_cast<const uchar4 *>(ip);
+        float4 ex = make_float4(0, 0, 0, 0);
+        if (ep) ex = *reinterpret_cast<const float4 *>(ep);
         float4 g;
-        g.x = in.x ? mb * (coef * acc4[0]) : 0.0f;
-        g.y = in.y ? mb * (coef * acc4[1]) : 0.0f;
-        g.z = in.z ? mb * (coef * acc4[2]) : 0.0f;
-        g.w = in.w ? mb * (coef * acc4[3]) : 0.0f;
+        g.x = in.x ? mb * (coef * acc4[0] + ex.x) : 0.0f;
+        g.y = in.y ? mb * (coef * acc4[1] + ex.y) : 0.0f;
+        g.z = in.z ? mb * (coef * acc4[2] + ex.z) : 0.0f;
+        g.w = in.w ? mb * (coef * acc4[3] + ex.w) : 0.0f;
         *reinterpret_cast<float4 *>(gp) = g;
     } else {
         for (int e = 0; e < count; ++e)
-            if (ox + e < a.w) gp[e] = ip[e] ? mb * (coef * acc4[e]) : 0.0f;
+            if (ox + e < a.w) gp[e] = ip[e] ? mb * (coef * acc4[e] + (ep ? ep[e] : 0.0f)) : 0.0f;
     }
 }
 
@@ -353,6 +357,7 @@ struct FoldArgs {
     int norm_parts;
     float *norm_out;
     const uint8_t *inside;
+    const float *g_extra;
     float *g_model_out;
     float scale, neg_b;
     int power, c, h, w, ph, pw, off, reach;
@@ -385,7 +390,9 @@ __global__ __launch_bounds__(NT) void k_blur_fold(FoldArgs f)
         for (int b = 0; b <= nx; ++b) acc += vp[(int64_t)(ps[a] + f.off) * f.pw + (qs[b] + f.off)];
     const int64_t o = (int64_t)i * f.w + j, hw = (int64_t)f.h * f.w;
     if constexpr (EPI)
-        f.g_model_out[((int64_t)n * 2 * f.c + ch) * hw + o] = f.inside[(int64_t)plane * hw + o] ? f.neg_b * (coef * acc) : 0.0f;
+        f.g_model_out[((int64_t)n * 2 * f.c + ch) * hw + o] =
+            f.inside[(int64_t)plane * hw + o]
+                ? f.neg_b * (coef * acc + (f.g_extra ? f.g_extra[(int64_t)plane * hw + o] : 0.0f)) : 0.0f;
     else
         f.g[(int64_t)plane * hw + o] = acc;
 }
@@ -543,7 +550,7 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     // 2. fold + epilogue
     FoldArgs f{};
     f.v = scratch; f.g = a.out; f.norm_in = a.norm_in; f.norm_partials = a.norm_partials; f.norm_parts = a.norm_parts;
-    f.norm_out = a.norm_out; f.inside = a.inside_r; f.g_model_out = a.g_model_out; f.scale = a.scale;
+    f.norm_out = a.norm_out; f.inside = a.inside_r; f.g_extra = a.g_extra; f.g_model_out = a.g_model_out; f.scale = a.scale;
     f.neg_b = -a.k.b; f.power = a.power; f.c = a.c; f.h = a.h; f.w = a.w; f.ph = ph; f.pw = pw; f.off = r4;
     f.reach = op->reach;
     const dim3 grid((unsigned)((a.h * a.w + NT - 1) / NT), (unsigned)a.planes);
@@ -612,10 +619,10 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, float *scratch, int64
     BlurArgs a{};
     a.x = b.resid;
     a.norm_in = b.norm; a.norm_partials = b.partials; a.norm_parts = b.parts; a.norm_out = b.norm_out;
-    a.inside_r = b.inside; a.g_model_out = b.g_model_out; a.scale = b.scale; a.power = b.power;
+    a.inside_r = b.inside; a.g_extra = b.g_extra; a.g_model_out = b.g_model_out; a.scale = b.scale; a.power = b.power;
     a.k = b.k;
     fill_geometry(a, b.n * b.c, b.c, b.h, b.w);
-    const bool vec = vec_ok(b.h, b.w, {b.resid, b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
+    const bool vec = vec_ok(b.h, b.w, {b.resid, b.g_model_out, b.g_extra}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
     return op->kind == OP_SEP && vec ? dispatch_sep_adj<true>(op, a, s)
                                      : launch_taps_adj<true>(op, a, vec, scratch, scratch_bytes, s);
 }

@@ -728,13 +728,21 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
             const int n = plane / a.c, ch = plane % a.c;
             float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
             const float mb = -a.k.b;
+            float4 ex[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[i] = make_float4(0, 0, 0, 0);
+            if (a.g_extra) {            // block-uniform: the semantic term's cotangent on x0_hat rides the same gate
+                const float *ep = a.g_extra + (int64_t)plane * hw + o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ex[i] = *reinterpret_cast<const float4 *>(ep + (unsigned)(i * a.w));
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float4 g;
-                g.x = gate[i].x ? mb * (coef * acc[i][0]) : 0.0f;
-                g.y = gate[i].y ? mb * (coef * acc[i][1]) : 0.0f;
-                g.z = gate[i].z ? mb * (coef * acc[i][2]) : 0.0f;
-                g.w = gate[i].w ? mb * (coef * acc[i][3]) : 0.0f;
+                g.x = gate[i].x ? mb * (coef * acc[i][0] + ex[i].x) : 0.0f;
+                g.y = gate[i].y ? mb * (coef * acc[i][1] + ex[i].y) : 0.0f;
+                g.z = gate[i].z ? mb * (coef * acc[i][2] + ex[i].z) : 0.0f;
+                g.w = gate[i].w ? mb * (coef * acc[i][3] + ex[i].w) : 0.0f;
                 *reinterpret_cast<float4 *>(gp + (unsigned)(i * a.w)) = g;
             }
         }

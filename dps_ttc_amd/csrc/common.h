@@ -221,6 +221,7 @@ struct StepBwdArgs {
     float *g_model_out;
     int64_t n, c, h, w;
     Coefs k;
+    const float *g_extra = nullptr;   // optional extra cotangent on x0_hat [n, c, h, w], added before the clamp gate
 };
 
 // blur.hip
@@ -259,7 +260,8 @@ int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, 
              int64_t n, int64_t m, hipStream_t s);
 // g_model_out[:, :c] = -b * (inside ? coef_p * g_x0 : 0),  g_x0 = A^T r
 int clamp_scale_to_eps(const float *g_x0, const float *norm, const uint8_t *inside, float scale, int power,
-                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s,
+                       const float *g_extra = nullptr);
 int step_update(const float *sample, const float *g_mo, const float *g_unet, float *x_next,
                 int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
 int plain_update(const float *sample, const float *ga, const float *gb, float *out, int64_t count, hipStream_t s);

@@ -209,20 +209,25 @@ int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, 
 __global__ __launch_bounds__(kThreads) void k_clamp_scale(const float *__restrict__ g_x0,
                                                           const float *__restrict__ norm,
                                                           const uint8_t *__restrict__ ins, float scale, int power,
-                                                          float *__restrict__ g_mo, int64_t chw, Coefs k)
+                                                          float *__restrict__ g_mo, int64_t chw, Coefs k,
+                                                          const float *__restrict__ g_extra)
 {
     const int64_t p = blockIdx.y, i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= chw) return;
     const float coef = norm_coef(norm[p], scale, power);  // g_x0 holds A^T r; cotangent is coef * A^T r
-    const float gp = ins[p * chw + i] ? coef * g_x0[p * chw + i] : 0.0f;
+    float g0 = coef * g_x0[p * chw + i];
+    if (g_extra) g0 += g_extra[p * chw + i];
+    const float gp = ins[p * chw + i] ? g0 : 0.0f;
     g_mo[p * 2 * chw + i] = -k.b * gp;
 }
 
 int clamp_scale_to_eps(const float *g_x0, const float *norm, const uint8_t *inside, float scale, int power,
-                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
+                       float *g_model_out, int64_t n, int64_t chw, const Coefs &k, hipStream_t s,
+                       const float *g_extra)
 {
     if (n == 0 || chw == 0) return DPSX_OK;
-    k_clamp_scale<<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, norm, inside, scale, power, g_model_out, chw, k);
+    k_clamp_scale<<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, norm, inside, scale, power, g_model_out, chw, k,
+                                                        g_extra);
     return check_launch();
 }
 
@@ -354,10 +359,12 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_bwd(StepBwdArgs a, const
     const uchar4 in = *reinterpret_cast<const uchar4 *>(a.inside + o);
     float4 g;
     // A^T = multiply by mask again; then clamp gate; then d/d eps = -b
-    g.x = in.x ? -a.k.b * (coef * __fsub_rn(yv.x, __fmul_rn(x0.x, mv.x)) * mv.x) : 0.0f;
-    g.y = in.y ? -a.k.b * (coef * __fsub_rn(yv.y, __fmul_rn(x0.y, mv.y)) * mv.y) : 0.0f;
-    g.z = in.z ? -a.k.b * (coef * __fsub_rn(yv.z, __fmul_rn(x0.z, mv.z)) * mv.z) : 0.0f;
-    g.w = in.w ? -a.k.b * (coef * __fsub_rn(yv.w, __fmul_rn(x0.w, mv.w)) * mv.w) : 0.0f;
+    float4 ex = make_float4(0, 0, 0, 0);
+    if (a.g_extra) ex = *reinterpret_cast<const float4 *>(a.g_extra + o);     // block-uniform
+    g.x = in.x ? -a.k.b * (coef * __fsub_rn(yv.x, __fmul_rn(x0.x, mv.x)) * mv.x + ex.x) : 0.0f;
+    g.y = in.y ? -a.k.b * (coef * __fsub_rn(yv.y, __fmul_rn(x0.y, mv.y)) * mv.y + ex.y) : 0.0f;
+    g.z = in.z ? -a.k.b * (coef * __fsub_rn(yv.z, __fmul_rn(x0.z, mv.z)) * mv.z + ex.z) : 0.0f;
+    g.w = in.w ? -a.k.b * (coef * __fsub_rn(yv.w, __fmul_rn(x0.w, mv.w)) * mv.w + ex.w) : 0.0f;
     *reinterpret_cast<float4 *>(a.g_model_out + p * 2 * chw + i) = g;
 }
 

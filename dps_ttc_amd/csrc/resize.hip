@@ -58,6 +58,7 @@ struct ResizeArgs {
     int norm_parts;
     float *norm_out;
     const uint8_t *inside_r;
+    const float *g_extra;     // optional extra cotangent on x0_hat (nullable)
     float *g_model_out;
     float scale;
     int power;
@@ -469,16 +470,19 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
             const uint8_t *ip = a.inside_r + (int64_t)plane * ihw + o;
             float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * ihw + o;
             const float mb = -a.k.b;
+            const float *ep = a.g_extra ? a.g_extra + (int64_t)plane * ihw + o : nullptr;
             if constexpr (VEC) {
                 const uchar4 in = *reinterpret_cast<const uchar4 *>(ip);
+                float4 ex = make_float4(0, 0, 0, 0);
+                if (ep) ex = *reinterpret_cast<const float4 *>(ep);
                 float4 r;
-                r.x = in.x ? mb * (coef * g[0]) : 0.0f;
-                r.y = in.y ? mb * (coef * g[1]) : 0.0f;
-                r.z = in.z ? mb * (coef * g[2]) : 0.0f;
-                r.w = in.w ? mb * (coef * g[3]) : 0.0f;
+                r.x = in.x ? mb * (coef * g[0] + ex.x) : 0.0f;
+                r.y = in.y ? mb * (coef * g[1] + ex.y) : 0.0f;
+                r.z = in.z ? mb * (coef * g[2] + ex.z) : 0.0f;
+                r.w = in.w ? mb * (coef * g[3] + ex.w) : 0.0f;
                 *reinterpret_cast<float4 *>(gp) = r;
             } else {
-                gp[0] = ip[0] ? mb * (coef * g[0]) : 0.0f;
+                gp[0] = ip[0] ? mb * (coef * g[0] + (ep ? ep[0] : 0.0f)) : 0.0f;
             }
         } else {
             float *gp = a.out + (int64_t)plane * ihw + o;
@@ -742,9 +746,9 @@ int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
     if (b.n == 0) return DPSX_OK;
     ResizeArgs a{};
     a.x = b.resid; a.norm_in = b.norm; a.norm_partials = b.partials; a.norm_parts = b.parts; a.norm_out = b.norm_out;
-    a.inside_r = b.inside; a.g_model_out = b.g_model_out;
+    a.inside_r = b.inside; a.g_extra = b.g_extra; a.g_model_out = b.g_model_out;
     a.scale = b.scale; a.power = b.power; a.c = (int)b.c; a.planes = (int)(b.n * b.c); a.k = b.k;
-    const bool vec = rz_vec(op, {b.g_model_out}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
+    const bool vec = rz_vec(op, {b.g_model_out, b.g_extra}) && (reinterpret_cast<uintptr_t>(b.inside) & 3u) == 0;
     return launch_adj<true>(op, a, vec, s);
 }
 

@@ -152,6 +152,7 @@ class GaussianDiffusion:
         self.last_semantic_distance = None
         self._ts_cache = {}
         self._bufs = None
+        self._step_semantic = None
 
     # -- RNG ---------------------------------------------------------------
     def _randn(self, like, stride=None):
@@ -261,7 +262,10 @@ class GaussianDiffusion:
         y = kernels.f32c(measurement, "measurement")
         kernels.step_fwd(handle, buf, xp, mo, noise, y, coefs)
         spec = method.fused_spec(beta_scale=self.betas[idx], t=idx / self.num_timesteps, **cond_kw)
-        kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], coefs)
+        g_sem, self._step_semantic = None, None
+        if "semantic" in spec:            # embedder forward + VJP on x0_hat (torch), between the two HIP halves
+            g_sem, self._step_semantic = spec["semantic"](buf.x0_hat)
+        kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], coefs, g_x0_extra=g_sem)
         g_unet = None
         if model_out.requires_grad:
             (g_unet,) = torch.autograd.grad(model_out, x_prev, grad_outputs=buf.g_model_out.to(model_out.dtype))
@@ -293,6 +297,8 @@ class GaussianDiffusion:
                     # the reference's q_sample draw (:224), result unused by ps*
                     self._randn(measurement, self.parity_measurement_stride)
                 img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise)
+                if self._step_semantic is not None:
+                    semantic = self._step_semantic
             else:
                 img = img.detach().requires_grad_()
                 time = torch.tensor([idx], device=img.device)
@@ -442,7 +448,7 @@ class SearchDDPM(DDPM):
             model_out = self._call_model(model, img, idx)
         if noise is None:
             noise = self._randn(img)
-        _, sample = kernels.posterior_fwd(img, model_out, noise, self.step_coefs[idx])
+        _, sample = kernels.posterior_fwd(img, model_out, noise, self.step_coefs[idx], want_x0=False)
         costs = handle.score(sample, measurement)
         if self.global_select is not None:
             return self.global_select(costs, sample), costs

@@ -29,14 +29,15 @@ def make_ddim_coefs(a, b, abar, abar_prev, eta, add_noise):
 
 
 # ------------------------------------------------------------------ S1
-def posterior_fwd(x_t, model_out, noise, coefs, want_inside=False):
-    """p_mean_variance + DDPM.p_sample (gaussian_diffusion.py:308-330, 466-476) -> (x0_hat, sample[, inside])."""
+def posterior_fwd(x_t, model_out, noise, coefs, want_inside=False, want_x0=True):
+    """p_mean_variance + DDPM.p_sample (gaussian_diffusion.py:308-330, 466-476) -> (x0_hat, sample[, inside]).
+    want_x0=False skips the x0_hat store (search_ddpm only consumes the sample): x0_hat is then None."""
     x_t, model_out = f32c(x_t, "x_t"), f32c(model_out, "model_out")
     noise = None if noise is None else f32c(noise, "noise")
     n, chw = x_t.shape[0], x_t[0].numel() if x_t.shape[0] else 0
     if model_out.shape[0] != n or (n and model_out[0].numel() != 2 * chw):
         raise ValueError(f"model_out {tuple(model_out.shape)} does not hold 2x the channels of x {tuple(x_t.shape)}")
-    x0, sample = torch.empty_like(x_t), torch.empty_like(x_t)
+    x0, sample = (torch.empty_like(x_t) if want_x0 else None), torch.empty_like(x_t)
     inside = torch.empty(x_t.shape, dtype=torch.uint8, device=x_t.device) if want_inside else None
     check(lib().dpsx_posterior_fwd_f32(ptr(x_t), ptr(model_out), ptr(noise), ptr(x0), ptr(sample), ptr(inside),
                                        n, chw, byref(coefs), stream_of(x_t)), "dpsx_posterior_fwd_f32")
@@ -339,15 +340,22 @@ def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False):
           "dpsx_step_fwd_f32")
 
 
-def step_bwd(handle, buf, y, scale, power, coefs):
+def step_bwd(handle, buf, y, scale, power, coefs, g_x0_extra=None):
+    """K2.  g_x0_extra: optional [N, C, H, W] cotangent on x0_hat of a further loss term (the semantic-guidance
+    term's VJP through the embedder), added to coef * A^T r before the clamp gate."""
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, buf.x0_hat.device)
     ready = getattr(buf, "norm_ready", True)
-    check(lib().dpsx_step_bwd_f32(handle._h, ptr(buf.resid), ptr(buf.norm) if ready else None, ptr(buf.norm),
-                                  ptr(buf.inside), ptr(buf.x0_hat),
-                                  ptr(y), y.shape[0], float(scale), int(power), ptr(buf.g_model_out),
-                                  n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(buf.x0_hat)),
-          "dpsx_step_bwd_f32")
+    if g_x0_extra is not None:
+        g_x0_extra = f32c(g_x0_extra, "g_x0_extra")
+        if tuple(g_x0_extra.shape) != (n, c, h, w):
+            raise ValueError("g_x0_extra must have the particle batch's shape")
+    check(lib().dpsx_step_bwd_extra_f32(handle._h, ptr(buf.resid), ptr(buf.norm) if ready else None, ptr(buf.norm),
+                                        ptr(buf.inside), ptr(buf.x0_hat),
+                                        ptr(y), y.shape[0], float(scale), int(power), ptr(g_x0_extra),
+                                        ptr(buf.g_model_out),
+                                        n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(buf.x0_hat)),
+          "dpsx_step_bwd_extra_f32")
     buf.norm_ready = True
 
 

@@ -160,6 +160,17 @@ int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *
                       int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
                       void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same launch with one more cotangent on x0_hat: g_x0_extra [n, c, h, w] (NULL = none) is added to
+ * coef * A^T r before the clamp gate and the -b scaling.  It carries the gradient of any further loss term that
+ * depends on x0_hat only -- the semantic-guidance term of PosteriorSamplingSemanticGuid.measurement_semantic_guidance
+ * (condition_methods.py:155-187: sem_guid_scale_t * ||emb(x0_hat) - emb_ref||^p, its VJP taken by the caller
+ * through the pluggable embedder) -- so that configuration also runs on the three fused launches. */
+int dpsx_step_bwd_extra_f32(dpsx_op *op, const void *resid, const float *norm, float *norm_out,
+                            const uint8_t *inside, const float *x0_hat, const float *y, int64_t y_n,
+                            float scale, int power, const float *g_x0_extra, float *g_model_out,
+                            int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
+                            void *workspace, int64_t workspace_bytes, void *stream);
+
 int dpsx_step_update_f32(const float *sample, const float *g_model_out, const float *g_unet,
                          float *x_next, int64_t n, int64_t chw, const dpsx_coefs *coefs_host,
                          void *stream);

@@ -287,11 +287,12 @@ def make_operator(name, **cfg):
 
 
 # ---------------------------------------------------------------- one DPS step
-def dps_step(op, x_prev, model_out, noise, y, coefs, scale=1.0, power=1, g_unet_fn=None):
+def dps_step(op, x_prev, model_out, noise, y, coefs, scale=1.0, power=1, g_unet_fn=None, g_x0_extra=None):
     """One step of the base loop with 'ps_semantic' (sem_guid_scale=0)  /  'ps':
     gaussian_diffusion.py:207-257 + condition_methods.py:145-187.
 
     g_unet_fn(g_model_out) -> J_model^T g  (the UNet VJP; zeros if None).
+    g_x0_extra: optional cotangent on x0_hat of a loss term beyond the measurement norm.
     Returns dict(x0_hat, sample, norm, grad, x_next, g_model_out, g_direct).
     """
     f = posterior_fwd(x_prev, model_out, noise, coefs)
@@ -299,6 +300,8 @@ def dps_step(op, x_prev, model_out, noise, y, coefs, scale=1.0, power=1, g_unet_
     r, norm = residual_norm(y, ax)
     g_ax = norm_bwd(r, norm, np.full(norm.shape, scale, dtype=np.float32), power)
     g_x0 = op.adjoint(g_ax.reshape(ax.shape), x_prev.shape[-2:])
+    if g_x0_extra is not None:      # cotangent of a further loss term on x0_hat (semantic guidance, :155-187)
+        g_x0 = (_f(g_x0) + _f(g_x0_extra)).astype(np.float32)
     g_direct, g_mo = posterior_bwd(g_x0, None, x_prev, model_out, noise, coefs)
     grad = g_direct if g_unet_fn is None else g_direct + _f(g_unet_fn(g_mo))
     x_next = update(f["sample"], grad)

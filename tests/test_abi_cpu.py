@@ -20,6 +20,7 @@ def test_header_declares_the_expected_surface():
     for must in ("dpsx_posterior_fwd_f32", "dpsx_posterior_bwd_f32", "dpsx_op_create_blur", "dpsx_op_create_resize",
                  "dpsx_op_create_mask", "dpsx_op_create_phase", "dpsx_op_forward_f32", "dpsx_op_adjoint_f32",
                  "dpsx_residual_norm_f32", "dpsx_norm_bwd_f32", "dpsx_step_fwd_f32", "dpsx_step_bwd_f32",
+                 "dpsx_step_bwd_extra_f32",
                  "dpsx_step_update_f32", "dpsx_update_f32", "dpsx_score_f32", "dpsx_argmin_f32", "dpsx_gather_f32",
                  "dpsx_replicate_f32"):
         assert must in names

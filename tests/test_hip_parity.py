@@ -275,7 +275,8 @@ def test_residual_norm_and_vjp(K, oracle):
 
 
 # ----------------------------------------------------------------- fused DPS step vs oracle
-def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False, ddim_eta=None):
+def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False, ddim_eta=None,
+                extra=False):
     rng = np.random.RandomState(seed)
     sched = oracle.tables.schedule(1000)
     c, ck = coefs_of(K, oracle, t, sched) if ddim_eta is None else ddim_coefs_of(K, oracle, t, ddim_eta, sched)
@@ -290,13 +291,15 @@ def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask
     y = orc.forward(truth)
     y = (y + 0.05 * rng.randn(*y.shape)).astype(np.float32)
     g_unet = (1e-2 * rng.randn(n, 3, hw, hw)).astype(np.float32)
-    ref = oracle.dps_step(orc, x_prev, mo, noise, y, c, scale=scale, power=power, g_unet_fn=lambda g: g_unet)
+    g_extra = (0.05 * rng.randn(n, 3, hw, hw)).astype(np.float32) if extra else None
+    ref = oracle.dps_step(orc, x_prev, mo, noise, y, c, scale=scale, power=power, g_unet_fn=lambda g: g_unet,
+                          g_x0_extra=g_extra)
     handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(dev(x_prev))
     buf = K.StepBuffers(handle, n, 3, hw, hw, DEV)
     K.step_fwd(handle, buf, dev(x_prev), dev(mo), dev(noise), dev(y), ck, finalize_norm=finalize)
     if finalize:        # norms already final after K1 (the stand-alone finalisation kernel)
         assert rel_l2(host(buf.norm), ref["norm"]) < TOL
-    K.step_bwd(handle, buf, dev(y), scale, power, ck)
+    K.step_bwd(handle, buf, dev(y), scale, power, ck, g_x0_extra=None if g_extra is None else dev(g_extra))
     x_next = K.step_update(buf, dev(g_unet), ck)
     np.testing.assert_array_equal(host(buf.x0_hat), ref["x0_hat"])
     np.testing.assert_array_equal(buf.inside.cpu().numpy(), ref["inside"])
@@ -328,6 +331,63 @@ def test_fused_step_ddim_vs_oracle(K, oracle, golden, name, hw, t, eta):
     g = golden("operators")
     mask = (np.random.RandomState(7).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
     _fused_case(K, oracle, name, 3, hw, t, 0.7, 1, seed=hw + t + 1, kernel=g["motion.kernel"], mask=mask, ddim_eta=eta)
+
+
+@pytest.mark.parametrize("name,hw", [("gauss", 64), ("gauss", 46), ("motion", 64), ("sr4", 64), ("sr4", 36), ("inpaint", 64),
+                                     ("phase", 32)])
+def test_fused_step_extra_cotangent_vs_oracle(K, oracle, golden, name, hw):
+    """dpsx_step_bwd_extra_f32: a further cotangent on x0_hat (the semantic term's) joins coef * A^T r before the gate"""
+    g = golden("operators")
+    mask = (np.random.RandomState(7).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    _fused_case(K, oracle, name, 3, hw, 600, 0.7, 1, seed=hw + 3, kernel=g["motion.kernel"], mask=mask, extra=True)
+    _fused_case(K, oracle, name, 2, hw, 0, 0.4, 2, seed=hw + 4, kernel=g["motion.kernel"], mask=mask, extra=True,
+                finalize=True)
+
+
+class _ToyEmbedder(torch.nn.Module):
+    """Stand-in for the face-embedding network (the reference's InceptionResnetV1 weights are not available
+    offline): a fixed random conv + pooling, differentiable, batch-independent."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(9)
+        self.w = torch.nn.Parameter(torch.randn(8, 3, 5, 5, generator=g) * 0.2, requires_grad=False)
+
+    def forward(self, x):
+        h = torch.nn.functional.conv2d(x, self.w, stride=2, padding=2)
+        return torch.tanh(h).mean(dim=(2, 3)) * 4.0
+
+
+@pytest.mark.parametrize("oname", ["gauss", "motion", "sr4", "inpaint"])
+def test_semantic_guidance_fused_matches_per_op(K, golden, oname):
+    """ps_semantic with an ACTIVE semantic term (pluggable embedder; parity with the reference's networks is unpinned):
+    the fused route (embedder VJP -> dpsx_step_bwd_extra_f32) and the per-op autograd route give the same loop."""
+    import functools
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.measurements import get_noise
+    g, gops = golden("loop"), golden("operators")
+    op, fkw = make_product_op(oname, hw=64, kernel=gops["motion.kernel"], mask=gops["inpaint.mask"])
+    emb = _ToyEmbedder().to(DEV)
+    ref_emb = emb(dev(g["gauss.r20.x_start"][:1]).tanh()).unsqueeze(0)
+    res = []
+    for fused in (True, False):
+        cm = get_conditioning_method("ps_semantic", op, get_noise("gaussian", sigma=0.05), scale=0.5,
+                                     sem_guid_scale=0.3, anneal_factor=4.0, norm_exp=2, embedder=emb,
+                                     guid_image_emb=ref_emb, guid_images=[0])
+        smp = _sampler("ddpm", "20")
+        if fused:
+            cond = functools.partial(cm.conditioning, **fkw) if fkw else cm.conditioning
+        else:
+            cond = lambda **kw: cm.conditioning(**kw, **fkw)          # foreign callable -> per-op autograd path
+        assert (smp._fusion_plan(cond, dev(g["gauss.r20.x_start"])) is not None) == fused
+        torch.manual_seed(3)
+        y = op.forward(dev(g["gauss.r20.x_start"][:1]).tanh(), **fkw).detach().contiguous()
+        img, dist, sem = smp.p_sample_loop(model=StandInModel().to(DEV), x_start=dev(g["gauss.r20.x_start"]).requires_grad_(),
+                                           measurement=y, measurement_cond_fn=cond, record=False, save_root=None)
+        res.append((host(img), host(dist), host(sem)))
+    assert res[0][2].shape == (4,) and np.all(res[0][2] > 0)
+    assert rel_l2(res[0][0], res[1][0]) < 1e-4
+    assert rel_l2(res[0][1], res[1][1]) < 1e-4 and rel_l2(res[0][2], res[1][2]) < 1e-4
 
 
 def test_fused_step_full_size_headline(K, oracle):

@@ -115,7 +115,16 @@ def test_fused_spec_and_fusion_planning():
     assert abs(sem.semantic_scale(1.0) - 0.0) < 1e-12
     sem2 = get_conditioning_method("ps_semantic", op, g, sem_guid_scale=0.01, anneal_factor=10.0, embedder=lambda x: x)
     assert abs(sem2.semantic_scale(0.0) - 0.01 * (1 + 9 / (1 + np.exp(-3.0)))) < 1e-12
-    assert sem2.fused_spec() is None                                                    # semantic term: autograd path
+    spec2 = sem2.fused_spec(t=0.5)            # active semantic term: its x0_hat cotangent rides the fused backward
+    assert spec2["scale"] == sem2.scale and spec2["power"] == 1 and callable(spec2["semantic"])
+    sem2.guid_image_emb = torch.zeros(1, 1, 3 * 4 * 4)
+    sem2.embedder = lambda x: x.reshape(x.shape[0], -1)
+    x0 = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(0))
+    g, d = spec2["semantic"](x0)
+    # loss = s_t * ||x0||_2 per particle  ->  gradient s_t * x0 / ||x0||
+    st = sem2.semantic_scale(0.5)
+    ref = st * x0 / x0.reshape(2, -1).norm(dim=1).view(2, 1, 1, 1)
+    assert torch.allclose(g, ref, atol=1e-6) and torch.allclose(d, x0.reshape(2, -1).norm(dim=1), atol=1e-6)
     m, kw = GaussianDiffusion._unwrap_cond_fn(functools.partial(functools.partial(ps.conditioning, mask=1), l1=2))
     assert m is ps and kw == {"mask": 1, "l1": 2}
     m, kw = GaussianDiffusion._unwrap_cond_fn(lambda **k: None)

@@ -34,7 +34,10 @@ def main():
                          rescale_timesteps=True, timestep_respacing="")
     x_t, ring, truth, meas_noise = bench.synth_inputs(n, 2, dev, 1234)
     yy = op.forward(truth.to(dev), **fkw).detach()
-    y = (yy + meas_noise.to(dev)[..., :yy.shape[-2], :yy.shape[-1]]).contiguous()
+    mn = meas_noise.to(dev)
+    if mn.shape[-1] < yy.shape[-1]:                      # phase retrieval measures on the oversampled grid
+        mn = 0.05 * torch.randn(yy.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    y = (yy + mn[..., :yy.shape[-2], :yy.shape[-1]]).contiguous()
     handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
     buf = kernels.StepBuffers(handle, n, 3, 256, 256, dev)
     ck = smp.step_coefs[500]

@@ -425,7 +425,7 @@ int64_t dpsx_step_resid_bytes(const dpsx_op *op, int64_t n, int64_t c, int64_t h
     if (m < 0) return DPSX_EINVAL;
     switch (op->kind) {
     case OP_MASK: return 256;                         // residual is recomputed from x0_hat
-    case OP_PHASE: return align256(n * m * 8);        // complex cotangent
+    case OP_PHASE: return phase_step_resid_bytes(op, n * c);   // padded real image + Hermitian half spectrum
     default: return align256(n * m * 4);
     }
 }

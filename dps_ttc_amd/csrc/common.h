@@ -287,5 +287,6 @@ int phase_step_fwd(dpsx_op *op, const float *x0_hat, const float *y, int64_t y_n
                    float *partials, int64_t n, int64_t c, hipStream_t s);
 int phase_step_bwd(dpsx_op *op, float *resid_c, float *g_x0, int64_t planes, hipStream_t s);
 int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c);
+int64_t phase_step_resid_bytes(const dpsx_op *op, int64_t planes);
 
 }  // namespace dpsx

@@ -22,23 +22,24 @@ constexpr int PT = 256;
 constexpr int kChunk = 4096;  // spectrum elements per block in the reducing pass
 
 struct PhaseHost {
-    std::map<int64_t, hipfftHandle> plans;  // batch -> plan
+    std::map<int64_t, hipfftHandle> plans;  // batch * 4 + kind -> plan   (kind: 0 C2C, 1 R2C, 2 C2R)
 };
 
 static PhaseHost *host_of(const dpsx_op *op) { return static_cast<PhaseHost *>(op->fft_plan); }
 
-static int get_plan(dpsx_op *op, int64_t planes, hipfftHandle *out)
+static int get_plan(dpsx_op *op, int64_t planes, hipfftHandle *out, int kind = 0)
 {
     PhaseHost *h = host_of(op);
-    auto it = h->plans.find(planes);
+    auto it = h->plans.find(planes * 4 + kind);
     if (it != h->plans.end()) { *out = it->second; return DPSX_OK; }
     const int s = (int)(op->pr_h + 2 * op->pr_pad);
     int dims[2] = {s, s};
     hipfftHandle plan;
-    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, s * s, nullptr, 1, s * s, HIPFFT_C2C, (int)planes) !=
-        HIPFFT_SUCCESS)
+    const hipfftType type = kind == 0 ? HIPFFT_C2C : (kind == 1 ? HIPFFT_R2C : HIPFFT_C2R);
+    // default (packed) layouts: real [s][s], half spectrum [s][s/2 + 1]
+    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, s * s, nullptr, 1, s * s, type, (int)planes) != HIPFFT_SUCCESS)
         return DPSX_ENOMEM;
-    h->plans[planes] = plan;
+    h->plans[planes * 4 + kind] = plan;
     *out = plan;
     return DPSX_OK;
 }
@@ -68,10 +69,21 @@ int64_t phase_workspace_bytes(const dpsx_op *op, int64_t planes)
     return (planes * s * s * 8 + 255) / 256 * 256;
 }
 
+// The fused step works on the Hermitian half: x0_hat is real, so Z[-k] = conj(Z[k]) and the s x (s/2 + 1) half
+// spectrum of an R2C transform carries everything; the real part of the inverse transform of the cotangent W is the
+// C2R transform of its Hermitian part  Wh[k] = (W[k] + conj(W[-k])) / 2 = (r(k) + r(-k)) / 2 * z[k] / |z[k]|.
+// Half the FFT work and half the spectrum traffic of the complex-to-complex form (which the plain operator calls keep).
 int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c)
 {
     const int64_t s = op->pr_h + 2 * op->pr_pad;
-    return c * ((s * s + kChunk - 1) / kChunk);
+    return c * ((s * (s / 2 + 1) + kChunk - 1) / kChunk);
+}
+
+// fused-step scratch: [planes][s][s] real | [planes][s][s/2 + 1] complex
+int64_t phase_step_resid_bytes(const dpsx_op *op, int64_t planes)
+{
+    const int64_t s = op->pr_h + 2 * op->pr_pad;
+    return (planes * s * s * 4 + 255) / 256 * 256 + (planes * s * (s / 2 + 1) * 8 + 255) / 256 * 256;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -155,6 +167,72 @@ __global__ __launch_bounds__(PT) void k_phase_crop(const float2 *__restrict__ v,
     g[plane * h * h + idx] = v[plane * s * s + (int64_t)i * s + j].x * (1.0f / (float)s);
 }
 
+// ---- Hermitian-half kernels of the fused step
+__global__ __launch_bounds__(PT) void k_phase_pre_real(const float *__restrict__ x, float *__restrict__ q, int h,
+                                                       int pad, int s)
+{
+    const int64_t plane = blockIdx.y;
+    const int idx = blockIdx.x * PT + threadIdx.x;
+    if (idx >= s * s) return;
+    const int u = idx / s, v = idx - u * s, half = s / 2;
+    int i = u + half, j = v + half;  // ifftshift
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    float val = 0.0f;
+    if (i >= pad && i < pad + h && j >= pad && j < pad + h) val = x[plane * h * h + (int64_t)(i - pad) * h + (j - pad)];
+    q[plane * s * s + idx] = val;
+}
+
+// z: [planes][s][s/2 + 1] from the R2C transform.  For k = (ky, kx <= s/2) and its mirror m = (-ky, -kx):
+// r(k) = y[shift k] - |z[k]|/s, r(m) = y[shift m] - |z[k]|/s; sums of squares over the FULL spectrum (the mirror
+// counts here unless it lies in the half itself, kx in {0, s/2}); z[k] <- (r(k) + r(m)) / 2 * z[k] / |z[k]|.
+__global__ __launch_bounds__(PT) void k_phase_post_half(float2 *__restrict__ z, const float *__restrict__ y, int y_n,
+                                                        int c, float *__restrict__ partials, int s)
+{
+    __shared__ float scratch[PT / kWave];
+    const int64_t plane = blockIdx.y;
+    const int hs = s / 2 + 1, half = s / 2;
+    const int64_t hh = (int64_t)s * hs, ss = (int64_t)s * s;
+    const float inv = 1.0f / (float)s;
+    const int n = (int)(plane / c), ch = (int)(plane % c);
+    const float *yp = y + ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * ss;
+    float acc = 0.0f;
+    const int base = blockIdx.x * kChunk;
+    for (int t = threadIdx.x; t < kChunk; t += PT) {
+        const int idx = base + t;
+        if (idx >= hh) break;
+        const int ky = idx / hs, kx = idx - ky * hs;
+        const int my = ky == 0 ? 0 : s - ky, mx = kx == 0 ? 0 : s - kx;          // the mirror frequency
+        int oy = ky + half, ox = kx + half, py = my + half, px = mx + half;      // fftshift of both
+        oy = oy >= s ? oy - s : oy; ox = ox >= s ? ox - s : ox;
+        py = py >= s ? py - s : py; px = px >= s ? px - s : px;
+        float2 zz = z[plane * hh + idx];
+        zz.x *= inv;
+        zz.y *= inv;
+        const float mag = sqrtf(zz.x * zz.x + zz.y * zz.y);
+        const float r1 = yp[(int64_t)oy * s + ox] - mag, r2 = yp[(int64_t)py * s + px] - mag;
+        acc = fmaf(r1, r1, acc);
+        if (kx != 0 && kx != half) acc = fmaf(r2, r2, acc);
+        const float f = mag == 0.0f ? 0.0f : 0.5f * (r1 + r2) / mag;  // torch: d|z| = 0 at z = 0
+        z[plane * hh + idx] = make_float2(f * zz.x, f * zz.y);
+    }
+    const float t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(PT) void k_phase_crop_real(const float *__restrict__ v, float *__restrict__ g, int h,
+                                                        int pad, int s)
+{
+    const int64_t plane = blockIdx.y;
+    const int idx = blockIdx.x * PT + threadIdx.x;
+    if (idx >= h * h) return;
+    const int a = idx / h, b = idx - a * h, half = s / 2;
+    int i = a + pad + half, j = b + pad + half;  // undo ifftshift
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    g[plane * h * h + idx] = v[plane * s * s + (int64_t)i * s + j] * (1.0f / (float)s);
+}
+
 // ---------------------------------------------------------------- host
 static int run_fft(dpsx_op *op, float2 *buf, int64_t planes, int dir, hipStream_t s)
 {
@@ -214,13 +292,19 @@ int phase_step_fwd(dpsx_op *op, const float *x0_hat, const float *y, int64_t y_n
 {
     const int64_t planes = n * c;
     if (planes == 0) return DPSX_OK;
-    const int sz = (int)(op->pr_h + 2 * op->pr_pad);
-    float2 *buf = reinterpret_cast<float2 *>(resid_c);
-    int rc = spectrum_of(op, x0_hat, buf, planes, s);
+    const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
+    float *real = resid_c;
+    float2 *half = reinterpret_cast<float2 *>(reinterpret_cast<char *>(resid_c) +
+                                              (planes * sz * sz * 4 + 255) / 256 * 256);
+    k_phase_pre_real<<<dim3((sz * sz + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(x0_hat, real, h, pad, sz);
+    int rc = check_launch();
     if (rc != DPSX_OK) return rc;
-    const unsigned chunks = (unsigned)((sz * sz + kChunk - 1) / kChunk);
-    k_phase_post<1><<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(buf, nullptr, nullptr, y, (int)y_n, (int)c,
-                                                                   partials, sz);
+    hipfftHandle plan;
+    if ((rc = get_plan(op, planes, &plan, 1)) != DPSX_OK) return rc;
+    if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    if (hipfftExecR2C(plan, real, reinterpret_cast<hipfftComplex *>(half)) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    const unsigned chunks = (unsigned)((sz * (sz / 2 + 1) + kChunk - 1) / kChunk);
+    k_phase_post_half<<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(half, y, (int)y_n, (int)c, partials, sz);
     return check_launch();
 }
 
@@ -228,10 +312,15 @@ int phase_step_bwd(dpsx_op *op, float *resid_c, float *g_x0, int64_t planes, hip
 {
     if (planes == 0) return DPSX_OK;
     const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
-    float2 *buf = reinterpret_cast<float2 *>(resid_c);
-    int rc = run_fft(op, buf, planes, HIPFFT_BACKWARD, s);
+    float *real = resid_c;
+    float2 *half = reinterpret_cast<float2 *>(reinterpret_cast<char *>(resid_c) +
+                                              (planes * sz * sz * 4 + 255) / 256 * 256);
+    hipfftHandle plan;
+    int rc = get_plan(op, planes, &plan, 2);
     if (rc != DPSX_OK) return rc;
-    k_phase_crop<<<dim3((h * h + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(buf, g_x0, h, pad, sz);
+    if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    if (hipfftExecC2R(plan, reinterpret_cast<hipfftComplex *>(half), real) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    k_phase_crop_real<<<dim3((h * h + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(real, g_x0, h, pad, sz);
     return check_launch();
 }
 

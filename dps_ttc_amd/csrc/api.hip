@@ -477,9 +477,7 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
         rc = residual_partials(y, y_n, x0_hat, static_cast<float *>(resid), ws.partials, n, chw, parts, s);
         break;
     case OP_PHASE:
-        rc = posterior_fwd(x_t, model_out, noise, x0_hat, sample, inside, n, chw, k, s);
-        if (rc != DPSX_OK) return rc;
-        rc = phase_step_fwd(op, x0_hat, y, y_n, static_cast<float *>(resid), ws.partials, n, c, s);
+        rc = phase_step_fwd(op, a, static_cast<float *>(resid), s);      // S1 + staging + R2C + residual / cotangent
         break;
     default: return DPSX_EUNSUPPORTED;
     }
@@ -536,6 +534,9 @@ int dpsx_step_bwd_extra_f32(dpsx_op *op, const void *resid, const float *norm, f
         return clamp_scale_to_eps(static_cast<const float *>(resid), norm, inside, scale, power, g_model_out, n,
                                   chw, k, s, g_x0_extra);
     case OP_PHASE:
+        if (phase_vec4_ok(op) && aligned16(g_model_out) && aligned16(g_x0_extra) &&
+            (reinterpret_cast<uintptr_t>(inside) & 3u) == 0)
+            return phase_step_bwd_fused(op, const_cast<float *>(static_cast<const float *>(resid)), b, s);
         rc = phase_step_bwd(op, const_cast<float *>(static_cast<const float *>(resid)), ws.img, n * c, s);
         if (rc != DPSX_OK) return rc;
         return clamp_scale_to_eps(ws.img, norm, inside, scale, power, g_model_out, n, chw, k, s, g_x0_extra);

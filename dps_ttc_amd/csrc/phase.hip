@@ -233,6 +233,79 @@ __global__ __launch_bounds__(PT) void k_phase_crop_real(const float *__restrict_
     g[plane * h * h + idx] = v[plane * s * s + (int64_t)i * s + j] * (1.0f / (float)s);
 }
 
+// S1 fused with the zero-pad + ifftshift staging of the fused step: one float4 unit of the padded (shifted) image per
+// lane; interior units do the posterior arithmetic (x0_hat, sample, gate out) and write x0_hat into the transform's
+// input, the others write zeros.  Needs h, pad, s/2 multiples of 4 (so a unit never straddles the wrap or the border).
+__global__ __launch_bounds__(PT) void k_phase_s1_pre(const float *__restrict__ x, const float *__restrict__ mo,
+                                                     const float *__restrict__ z, float *__restrict__ x0o,
+                                                     float *__restrict__ so, uint8_t *__restrict__ ins,
+                                                     float *__restrict__ q, int h, int pad, int s, int c, Coefs k)
+{
+    const int64_t plane = blockIdx.y;
+    const int unit = blockIdx.x * PT + threadIdx.x, su = s / 4;
+    if (unit >= s * su) return;
+    const int u = unit / su, v = (unit - u * su) * 4, half = s / 2;
+    int i = u + half, j = v + half;
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    float4 val = make_float4(0, 0, 0, 0);
+    if (i >= pad && i < pad + h && j >= pad && j < pad + h) {
+        const int64_t hw = (int64_t)h * h, o = plane * hw + (int64_t)(i - pad) * h + (j - pad);
+        const int64_t n = plane / c, ch = plane % c;
+        const int64_t e = (n * 2 * c + ch) * hw + (int64_t)(i - pad) * h + (j - pad);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+        const float4 ev = *reinterpret_cast<const float4 *>(mo + e);
+        float4 vv = make_float4(0, 0, 0, 0), zv = vv;
+        if (k.add_noise & 1) {
+            vv = *reinterpret_cast<const float4 *>(mo + e + (int64_t)c * hw);
+            zv = *reinterpret_cast<const float4 *>(z + o);
+        }
+        bool b0, b1, b2, b3;
+        float4 sm;
+        val.x = post_x0(xv.x, ev.x, k, b0);
+        val.y = post_x0(xv.y, ev.y, k, b1);
+        val.z = post_x0(xv.z, ev.z, k, b2);
+        val.w = post_x0(xv.w, ev.w, k, b3);
+        sm.x = post_sample(xv.x, val.x, vv.x, zv.x, k);
+        sm.y = post_sample(xv.y, val.y, vv.y, zv.y, k);
+        sm.z = post_sample(xv.z, val.z, vv.z, zv.z, k);
+        sm.w = post_sample(xv.w, val.w, vv.w, zv.w, k);
+        *reinterpret_cast<float4 *>(x0o + o) = val;
+        *reinterpret_cast<float4 *>(so + o) = sm;
+        *reinterpret_cast<uchar4 *>(ins + o) = make_uchar4(b0, b1, b2, b3);
+    }
+    *reinterpret_cast<float4 *>(q + plane * s * s + (int64_t)u * s + v) = val;
+}
+
+// crop + clamp gate + -b * coef (+ the optional extra cotangent) of the backward half in one pass over the image
+__global__ __launch_bounds__(PT) void k_phase_crop_clamp(const float *__restrict__ v, const float *__restrict__ norm,
+                                                         const uint8_t *__restrict__ ins,
+                                                         const float *__restrict__ g_extra, float scale, int power,
+                                                         float neg_b, float *__restrict__ g_mo, int h, int pad, int s,
+                                                         int c)
+{
+    const int64_t plane = blockIdx.y;
+    const int unit = blockIdx.x * PT + threadIdx.x, hu = h / 4;
+    if (unit >= h * hu) return;
+    const int a = unit / hu, b = (unit - a * hu) * 4, half = s / 2;
+    int i = a + pad + half, j = b + pad + half;
+    i = i >= s ? i - s : i;
+    j = j >= s ? j - s : j;
+    const float4 t = *reinterpret_cast<const float4 *>(v + plane * s * s + (int64_t)i * s + j);
+    const int64_t n = plane / c, ch = plane % c, hw = (int64_t)h * h, o = plane * hw + (int64_t)a * h + b;
+    const float nv = norm[n];
+    const float coef = (power == 2 ? -2.0f * scale : (nv == 0.0f ? 0.0f : -scale / nv)) * (1.0f / (float)s);
+    const uchar4 in = *reinterpret_cast<const uchar4 *>(ins + o);
+    float4 ex = make_float4(0, 0, 0, 0);
+    if (g_extra) ex = *reinterpret_cast<const float4 *>(g_extra + o);
+    float4 g;
+    g.x = in.x ? neg_b * (coef * t.x + ex.x) : 0.0f;
+    g.y = in.y ? neg_b * (coef * t.y + ex.y) : 0.0f;
+    g.z = in.z ? neg_b * (coef * t.z + ex.z) : 0.0f;
+    g.w = in.w ? neg_b * (coef * t.w + ex.w) : 0.0f;
+    *reinterpret_cast<float4 *>(g_mo + (n * 2 * c + ch) * hw + (int64_t)a * h + b) = g;
+}
+
 // ---------------------------------------------------------------- host
 static int run_fft(dpsx_op *op, float2 *buf, int64_t planes, int dir, hipStream_t s)
 {
@@ -287,24 +360,62 @@ int phase_adjoint(dpsx_op *op, const float *u, const float *x, float *g, int64_t
     return check_launch();
 }
 
-int phase_step_fwd(dpsx_op *op, const float *x0_hat, const float *y, int64_t y_n, float *resid_c,
-                   float *partials, int64_t n, int64_t c, hipStream_t s)
+bool phase_vec4_ok(const dpsx_op *op)
 {
-    const int64_t planes = n * c;
+    const int64_t h = op->pr_h, pad = op->pr_pad, sz = h + 2 * pad;
+    return h % 4 == 0 && pad % 4 == 0 && (sz / 2) % 4 == 0;
+}
+
+int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_t s)
+{
+    const int64_t n = f.n, c = f.c, planes = n * c;
     if (planes == 0) return DPSX_OK;
     const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
     float *real = resid_c;
     float2 *half = reinterpret_cast<float2 *>(reinterpret_cast<char *>(resid_c) +
                                               (planes * sz * sz * 4 + 255) / 256 * 256);
-    k_phase_pre_real<<<dim3((sz * sz + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(x0_hat, real, h, pad, sz);
-    int rc = check_launch();
+    int rc;
+    const bool vec = phase_vec4_ok(op) && aligned16(f.x_t) && aligned16(f.model_out) && aligned16(f.noise) &&
+                     aligned16(f.x0_hat) && aligned16(f.sample) && (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
+    if (vec) {      // S1 and the transform's input staging in one pass
+        k_phase_s1_pre<<<dim3((sz * (sz / 4) + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(
+            f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, real, h, pad, sz, (int)c, f.k);
+        rc = check_launch();
+    } else {
+        rc = posterior_fwd(f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, n, c * h * h, f.k, s);
+        if (rc != DPSX_OK) return rc;
+        k_phase_pre_real<<<dim3((sz * sz + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(f.x0_hat, real, h, pad, sz);
+        rc = check_launch();
+    }
     if (rc != DPSX_OK) return rc;
+    const float *y = f.y;
+    const int64_t y_n = f.y_n;
+    float *partials = f.partials;
     hipfftHandle plan;
     if ((rc = get_plan(op, planes, &plan, 1)) != DPSX_OK) return rc;
     if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
     if (hipfftExecR2C(plan, real, reinterpret_cast<hipfftComplex *>(half)) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
     const unsigned chunks = (unsigned)((sz * (sz / 2 + 1) + kChunk - 1) / kChunk);
     k_phase_post_half<<<dim3(chunks, (unsigned)planes), PT, 0, s>>>(half, y, (int)y_n, (int)c, partials, sz);
+    return check_launch();
+}
+
+// the whole backward half when the 16-byte form applies: C2R, then crop + gate + scaling in one pass
+int phase_step_bwd_fused(dpsx_op *op, float *resid_c, const StepBwdArgs &b, hipStream_t s)
+{
+    const int64_t planes = b.n * b.c;
+    if (planes == 0) return DPSX_OK;
+    const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
+    float *real = resid_c;
+    float2 *half = reinterpret_cast<float2 *>(reinterpret_cast<char *>(resid_c) +
+                                              (planes * sz * sz * 4 + 255) / 256 * 256);
+    hipfftHandle plan;
+    int rc = get_plan(op, planes, &plan, 2);
+    if (rc != DPSX_OK) return rc;
+    if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    if (hipfftExecC2R(plan, reinterpret_cast<hipfftComplex *>(half), real) != HIPFFT_SUCCESS) return DPSX_ELAUNCH;
+    k_phase_crop_clamp<<<dim3((h * (h / 4) + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(
+        real, b.norm, b.inside, b.g_extra, b.scale, b.power, -b.k.b, b.g_model_out, h, pad, sz, (int)b.c);
     return check_launch();
 }
 

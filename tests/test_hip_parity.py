@@ -194,6 +194,32 @@ def test_blur_other_radii(K, oracle, ks, sigma):
     assert rel_l2(host(h.adjoint(dev(x), in_hw=(80, 72))), oracle.blur_adj(x, k2)) < TOL
 
 
+@pytest.mark.parametrize("hw", [(128, 192), (192, 64), (64, 128)])
+@pytest.mark.parametrize("ks,sigma", [(9, 1.0), (25, 2.0), (61, 3.0), (61, 7.5)])
+def test_blur_regular_non_square(K, oracle, hw, ks, sigma):
+    """the branch-free loader / in-window folds of the separable kernels on multi-tile non-square images (one, two and
+    three tiles per axis), every radius bucket; plus the fused step there (x0_hat halo recomputed from neighbours)"""
+    rng = np.random.RandomState(ks + hw[0])
+    k2 = oracle.tables.gaussian_kernel2d(ks, sigma)
+    k2 = (k2 * (1.0 + 0.3 * np.linspace(-1, 1, ks))[None, :]).astype(np.float32)
+    h = K.OpHandle.blur(k2, DEV)
+    assert h.kind == K._lib.KIND_SEP
+    x = rng.randn(1, 3, *hw).astype(np.float32)
+    assert rel_l2(host(h.forward(dev(x))), oracle.blur_fwd(x, k2)) < TOL
+    assert rel_l2(host(h.adjoint(dev(x), in_hw=hw)), oracle.blur_adj(x, k2)) < TOL
+    # fused forward half against the un-fused composition on the GPU (S1 then the plain operator)
+    _, ck = coefs_of(K, oracle, 500)
+    xt, mo, z = dev(rng.randn(2, 3, *hw).astype(np.float32)), dev(rng.randn(2, 6, *hw).astype(np.float32) * 0.3), \
+        dev(rng.randn(2, 3, *hw).astype(np.float32))
+    y = dev(rng.randn(1, 3, *hw).astype(np.float32))
+    buf = K.StepBuffers(h, 2, 3, hw[0], hw[1], DEV)
+    K.step_fwd(h, buf, xt, mo, z, y, ck, finalize_norm=True)
+    x0, sm = K.posterior_fwd(xt, mo, z, ck)
+    assert torch.equal(buf.x0_hat, x0) and torch.equal(buf.sample, sm)
+    r = (y - h.forward(x0)).reshape(2, -1)
+    assert rel_l2(host(buf.norm), host(r.norm(dim=1))) < TOL
+
+
 def test_blur_rejects_pad_not_smaller_than_image(K, oracle):
     h = K.OpHandle.blur(oracle.tables.gaussian_kernel2d(61, 3.0), DEV)
     with pytest.raises(K._lib.DpsxError):
@@ -213,6 +239,20 @@ def test_resize_vs_oracle(K, oracle, factor, hw):
     assert rel_l2(host(y), orc.forward(x)) < TOL
     u = rng.randn(*y.shape).astype(np.float32)
     assert rel_l2(host(op.hip_handle().adjoint(dev(u), in_hw=(hw, hw))), orc.adjoint(u, (hw, hw))) < TOL
+
+
+@pytest.mark.parametrize("factor,shape", [(4, (128, 256)), (4, (256, 64)), (8, (64, 256)), (4, (48, 128))])
+def test_resize_non_square_vs_oracle(K, oracle, factor, shape):
+    """row-streaming forward / register-table adjoint on non-square images (wu = 64, 16, 32: 1, 4, 2 rows per wave-step)"""
+    from dps_ttc_amd.measurements import get_operator
+    rng = np.random.RandomState(factor + shape[0])
+    op = get_operator("super_resolution", in_shape=(1, 3) + shape, scale_factor=factor, device=DEV)
+    orc = oracle.make_operator("super_resolution", in_shape=(1, 3) + shape, scale_factor=factor)
+    x = rng.randn(2, 3, *shape).astype(np.float32)
+    y = op.forward(dev(x))
+    assert rel_l2(host(y), orc.forward(x)) < TOL
+    u = rng.randn(*y.shape).astype(np.float32)
+    assert rel_l2(host(op.hip_handle().adjoint(dev(u), in_hw=shape)), orc.adjoint(u, shape)) < TOL
 
 
 def test_inpainting_requires_mask():

@@ -52,7 +52,7 @@ struct BlurArgs {
     // generic taps
     const TapRun *runs;   // vertical runs of <= 4 taps (forward table, or the adjoint's negated / reversed one)
     int nruns;
-    int dbg;   // diagnostic phase mask (env DPSX_DBG), 0 in production
+    int dbg;   // phase-ablation mask: 0 unless built with -DDPSX_ABLATION=1 (see blur_sep.h)
     // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
     // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
     int src_h, src_w, src_off;
@@ -412,8 +412,12 @@ static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int
     a.c = (int)c; a.h = (int)h; a.w = (int)w; a.planes = (int)planes;
     a.tiles_x = (int)((w + TW - 1) / TW);
     a.tiles_y = (int)((h + TH - 1) / TH);
-    static const int dbg = getenv("DPSX_DBG") ? atoi(getenv("DPSX_DBG")) : 0;
+#if defined(DPSX_ABLATION) && DPSX_ABLATION
+    static const int dbg = getenv("DPSX_DBG") ? atoi(getenv("DPSX_DBG")) : 0;   // ablation build only (blur_sep.h)
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     a.src_h = (int)h; a.src_w = (int)w; a.src_off = 0;
 }
 

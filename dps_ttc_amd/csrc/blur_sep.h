@@ -23,6 +23,14 @@ __device__ __forceinline__ int fold_sources(int i, int n, int R, int (&p)[2])
     return cnt;
 }
 
+// Phase ablation for tools/abl.sh (skip a pass / the loader / the epilogue, force the general loader or folds):
+// compiled in only with -DDPSX_ABLATION=1 (make EXTRA=...), then selected at run time by the DPSX_DBG mask;
+// in the product build ABL() is the constant false and every such branch folds away.
+#ifndef DPSX_ABLATION
+#define DPSX_ABLATION 0
+#endif
+#define ABL(bit) (DPSX_ABLATION && (a.dbg & (bit)))
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -531,22 +539,22 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    const bool regular = a.h % TH == 0 && a.w % TW == 0 && RR < a.h && RR < a.w && !(a.dbg & 128);
+    const bool regular = a.h % TH == 0 && a.w % TW == 0 && RR < a.h && RR < a.w && !ABL(128);
     if (regular) load_region_reg<RR, POST, true>(s, h0, w0, a, plane);
-    else if (!(a.dbg & 4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
+    else if (!ABL(4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
     else for (int i = threadIdx.x; i < G::RH * G::SW; i += NT) s[i] = (float)i;
     __syncthreads();
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ox = w0 + 4 * cg;
-    if (!(a.dbg & 1)) hpass_inplace<RR>(s, taps.h);
+    if (!ABL(1)) hpass_inplace<RR>(s, taps.h);
     __syncthreads();
     float acc[4][4];
-    if (!(a.dbg & 2)) vpass_regs<RR>(s, acc, rg, cg, taps.v);
+    if (!ABL(2)) vpass_regs<RR>(s, acc, rg, cg, taps.v);
     else for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e];
     float ss = 0.0f;
     if (RESID && regular) {
         // straight-line epilogue: the four measurement rows are fetched together (one wait), then r = y - A(x0_hat)
-        if (!(a.dbg & 8)) {
+        if (!ABL(8)) {
             const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + 4 * rg) * a.w + ox);
             const int n = plane / a.c, ch = plane % a.c;
             const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + o;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
                 ss += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;   // same order as resid_epilogue
             }
         }
-    } else if (ox < a.w && !(a.dbg & 8)) {
+    } else if (ox < a.w && !ABL(8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = h0 + 4 * rg + i;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
     float coef = 0.0f;
-    const bool regular = a.h % TH == 0 && a.w % TW == 0 && !(a.dbg & 128);
+    const bool regular = a.h % TH == 0 && a.w % TW == 0 && !ABL(128);
     const bool norm_split = EPI && !a.norm_in && regular && a.norm_parts <= 4 * kWave;
     NormPartials np;
     if constexpr (EPI) {
@@ -612,8 +620,8 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     const bool last_x = w0 + TW >= a.w, last_y = h0 + TH >= a.h;
     const bool wfast = (lfold != rfold) && (lfold ? a.w >= RR + 1 : (last_x && a.w - w0 == TW));
     const bool hfast = (tfold != bfold) && (tfold ? a.h >= RR + 1 : (last_y && a.h - h0 == TH));
-    const bool wslow = (lfold || rfold) && !wfast && !(a.dbg & 16), hslow = (tfold || bfold) && !hfast && !(a.dbg & 16);
-    const bool wfast_ = wfast && !(a.dbg & 32), hfast_ = hfast && !(a.dbg & 32);
+    const bool wslow = (lfold || rfold) && !wfast && !ABL(16), hslow = (tfold || bfold) && !hfast && !ABL(16);
+    const bool wfast_ = wfast && !ABL(32), hfast_ = hfast && !ABL(32);
     if (wslow || hslow)
         for (int i = threadIdx.x; i <= 2 * RR; i += NT) {
             s_th[i] = taps.h[i];
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
         for (int i = 0; i < 4; ++i) gate[i] = *reinterpret_cast<const uchar4 *>(ip + (unsigned)(i * a.w));
     }
     if (regular) load_region_reg<RR, false, false>(s, h0, w0, a, plane);
-    else if (!(a.dbg & 4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
+    else if (!ABL(4)) load_region_fast<RR, false, false>(s, h0, w0, a, plane);
     if constexpr (EPI) { if (norm_split) particle_norm_reduce(np, a.norm_parts, s_th + 160); }
     __syncthreads();
     if constexpr (EPI) {
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
         }
         __syncthreads();
     }
-    if (a.dbg & 1) {}
+    if ABL(1) {}
     else if (wfast_ && lfold) hpass_inplace<RR, 1>(s, taps.h);
     else if (wfast_) hpass_inplace<RR, 2>(s, taps.h);
     else hpass_inplace<RR, 0>(s, taps.h);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     }
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     float acc[4][4];
-    if (a.dbg & 2) { for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e]; }
+    if ABL(2) { for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = s[(4 * rg + i + RR) * G::SW + 4 * cg + e]; }
     else if (hfast_ && tfold) vpass_regs<RR, 1>(s, acc, rg, cg, taps.v);
     else if (hfast_) vpass_regs<RR, 2>(s, acc, rg, cg, taps.v);
     else vpass_regs<RR, 0>(s, acc, rg, cg, taps.v);
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
     }
     const int ox = w0 + 4 * cg;
     if (EPI && regular) {
-        if (!(a.dbg & 8)) {
+        if (!ABL(8)) {
             const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + 4 * rg) * a.w + ox);
             const int n = plane / a.c, ch = plane % a.c;
             float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps
                 *reinterpret_cast<float4 *>(gp + (unsigned)(i * a.w)) = g;
             }
         }
-    } else if (ox < a.w && !(a.dbg & 8)) {
+    } else if (ox < a.w && !ABL(8)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
     }

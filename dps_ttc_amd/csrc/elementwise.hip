@@ -377,38 +377,48 @@ int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s)
 
 // ===================================================================== select
 // torch.argmin: first minimum; NaN is the minimum.  One block; n is small (<= a few thousand).
+// (value, index) pairs are reduced with a total order -- NaN before everything, then the smaller value, then the
+// smaller index -- by wave shuffles and one LDS hop, so the result does not depend on the reduction shape.
+struct ArgMin {
+    float v;
+    int64_t i;   // -1: empty
+};
+
+__device__ __forceinline__ bool argmin_better(const ArgMin &a, const ArgMin &b)   // a strictly before b
+{
+    if (a.i < 0) return false;
+    if (b.i < 0) return true;
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an != bn) return an;
+    if (an) return a.i < b.i;
+    return a.v < b.v || (a.v == b.v && a.i < b.i);
+}
+
 __global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v, int64_t n, int64_t *__restrict__ out)
 {
-    __shared__ float s_val[kThreads];
-    __shared__ int64_t s_idx[kThreads];
-    float best = 0.0f;
-    int64_t bi = -1;
-    bool best_nan = false;
+    __shared__ float s_val[kThreads / kWave];
+    __shared__ int64_t s_idx[kThreads / kWave];
+    ArgMin best{0.0f, -1};
     for (int64_t i = threadIdx.x; i < n; i += kThreads) {
-        const float x = v[i];
-        const bool xn = x != x;
-        if (bi < 0 || (!best_nan && (xn || x < best))) { best = x; bi = i; best_nan = xn; }
+        const ArgMin c{v[i], i};
+        if (argmin_better(c, best)) best = c;
     }
-    s_val[threadIdx.x] = best;
-    s_idx[threadIdx.x] = bi;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        ArgMin c;
+        c.v = __shfl_down(best.v, o, kWave);
+        c.i = __shfl_down(best.i, o, kWave);
+        if (argmin_better(c, best)) best = c;
+    }
+    const int wave = threadIdx.x / kWave;
+    if (threadIdx.x % kWave == 0) { s_val[wave] = best.v; s_idx[wave] = best.i; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float b = 0.0f;
-        int64_t ix = -1;
-        bool bn = false;
-        for (int t = 0; t < kThreads; ++t) {
-            const int64_t j = s_idx[t];
-            if (j < 0) continue;
-            const float x = s_val[t];
-            const bool xn = x != x;
-            bool take;
-            if (ix < 0) take = true;
-            else if (bn) take = xn && j < ix;
-            else if (xn) take = true;
-            else take = x < b || (x == b && j < ix);
-            if (take) { b = x; ix = j; bn = xn; }
+        for (int w = 1; w < kThreads / kWave; ++w) {
+            const ArgMin c{s_val[w], s_idx[w]};
+            if (argmin_better(c, best)) best = c;
         }
-        *out = ix < 0 ? 0 : ix;
+        *out = best.i < 0 ? 0 : best.i;
     }
 }
 

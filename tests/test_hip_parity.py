@@ -658,6 +658,15 @@ def test_argmin_gather_replicate(K, oracle, golden):
     big[4097] = -1.0
     big[4999] = -1.0
     assert int(K.argmin(big)) == 4097 == int(torch.argmin(big))
+    nn = torch.full((300,), float("nan"), device=DEV)
+    assert int(K.argmin(nn)) == 0
+    v3 = torch.rand(300, device=DEV)
+    v3[[77, 200, 299]] = float("nan")
+    assert int(K.argmin(v3)) == 77                                # first NaN wins, as torch.argmin
+    assert int(K.argmin(torch.tensor([5.0], device=DEV))) == 0
+    for n in (2, 63, 64, 65, 256, 257, 1000):
+        r = torch.randn(n, device=DEV).round(decimals=1)          # plenty of ties
+        assert int(K.argmin(r)) == int(torch.argmin(r))
     src = torch.randn(6, 3, 10, 7, device=DEV)                   # chw not a multiple of 4 -> scalar kernel
     ids = torch.tensor([5, 5, 0, 3], device=DEV)
     assert torch.equal(K.gather(src, ids), src[ids])

@@ -607,7 +607,7 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
     // ---- adjoint blocking
     int best_ti = 0;
     std::vector<int> alo, acnt;
-    for (int ti = 32; ti >= 1; ti >>= 1) {
+    for (int ti = 64; ti >= 1; ti >>= 1) {
         const int nblk = (d.in_h + ti - 1) / ti;
         std::vector<int> lo((size_t)nblk), cnt((size_t)nblk);
         int maxrows = 1;

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is git-ignored (it ships to the GPU box with the snapshot): build it for gfx950 if this
+    checkout does not have it yet (hipcc cross-compiles without a GPU, about a minute).  The product code itself never
+    builds on demand -- it fails loudly when the library is missing."""
+    so = os.path.join(ROOT, "dps_ttc_amd", "lib", "libdpsx.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
+
+
 class Fixture:
     """Lazy view over one tests/golden/*.npz (allow_pickle=False: data only)."""
 

@@ -537,6 +537,7 @@ int dpsx_step_bwd_extra_f32(dpsx_op *op, const void *resid, const float *norm, f
         if (phase_vec4_ok(op) && aligned16(g_model_out) && aligned16(g_x0_extra) &&
             (reinterpret_cast<uintptr_t>(inside) & 3u) == 0)
             return phase_step_bwd_fused(op, const_cast<float *>(static_cast<const float *>(resid)), b, s);
+        if (phase_is_spectral(op)) return DPSX_EUNSUPPORTED;     // its buffers have no unaligned form
         rc = phase_step_bwd(op, const_cast<float *>(static_cast<const float *>(resid)), ws.img, n * c, s);
         if (rc != DPSX_OK) return rc;
         return clamp_scale_to_eps(ws.img, norm, inside, scale, power, g_model_out, n, chw, k, s, g_x0_extra);

@@ -15,6 +15,7 @@
 #include <map>
 
 #include "common.h"
+#include "phase_fft.h"
 
 namespace dpsx {
 
@@ -23,9 +24,18 @@ constexpr int kChunk = 4096;  // spectrum elements per block in the reducing pas
 
 struct PhaseHost {
     std::map<int64_t, hipfftHandle> plans;  // batch * 4 + kind -> plan   (kind: 0 C2C, 1 R2C, 2 C2R)
+    float2 *d_tw = nullptr;                 // exp(-2 pi i t / 384) for the hand-written spectral step
 };
 
 static PhaseHost *host_of(const dpsx_op *op) { return static_cast<PhaseHost *>(op->fft_plan); }
+
+// the hand-written three-pass spectral step (phase_fft.h) covers the BASELINE geometry: 256 x 256, oversample 2.0
+static bool spectral(const dpsx_op *op)
+{
+    static const bool off = getenv("DPSX_PHASE_LIBRARY_FFT") != nullptr;      // A/B switch for tools/kbench.py
+    return !off && op->pr_h == prfft::IMG && op->pr_pad == prfft::PADW && host_of(op) && host_of(op)->d_tw;
+}
+
 
 static int get_plan(dpsx_op *op, int64_t planes, hipfftHandle *out, int kind = 0)
 {
@@ -50,6 +60,17 @@ int phase_create(dpsx_op *op)
     op->has_plan = true;
     hipfftHandle p;
     int rc = get_plan(op, op->pr_planes, &p);  // build the plan for the expected batch up front
+    if (rc == DPSX_OK && op->pr_h == prfft::IMG && op->pr_pad == prfft::PADW) {
+        float2 tw[prfft::N];
+        for (int t = 0; t < prfft::N; ++t) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)prfft::N;
+            tw[t] = make_float2((float)cos(a), (float)sin(a));
+        }
+        PhaseHost *h = host_of(op);
+        if (hipMalloc((void **)&h->d_tw, sizeof(tw)) != hipSuccess ||
+            hipMemcpy(h->d_tw, tw, sizeof(tw), hipMemcpyHostToDevice) != hipSuccess)
+            rc = DPSX_ENOMEM;
+    }
     if (rc != DPSX_OK) phase_destroy(op);
     return rc;
 }
@@ -59,6 +80,7 @@ void phase_destroy(dpsx_op *op)
     PhaseHost *h = host_of(op);
     if (!h) return;
     for (auto &kv : h->plans) (void)hipfftDestroy(kv.second);
+    if (h->d_tw) (void)hipFree(h->d_tw);
     delete h;
     op->fft_plan = nullptr;
 }
@@ -76,6 +98,7 @@ int64_t phase_workspace_bytes(const dpsx_op *op, int64_t planes)
 int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c)
 {
     const int64_t s = op->pr_h + 2 * op->pr_pad;
+    if (spectral(op)) return c * ((prfft::HS + prfft::CT - 1) / prfft::CT);    // one partial per column tile
     return c * ((s * (s / 2 + 1) + kChunk - 1) / kChunk);
 }
 
@@ -360,6 +383,8 @@ int phase_adjoint(dpsx_op *op, const float *u, const float *x, float *g, int64_t
     return check_launch();
 }
 
+bool phase_is_spectral(const dpsx_op *op) { return spectral(op); }
+
 bool phase_vec4_ok(const dpsx_op *op)
 {
     const int64_t h = op->pr_h, pad = op->pr_pad, sz = h + 2 * pad;
@@ -377,6 +402,18 @@ int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_
     int rc;
     const bool vec = phase_vec4_ok(op) && aligned16(f.x_t) && aligned16(f.model_out) && aligned16(f.noise) &&
                      aligned16(f.x0_hat) && aligned16(f.sample) && (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
+    if (spectral(op) && !vec) return DPSX_EUNSUPPORTED;   // the partial-sum layout is fixed per operator
+    if (vec && spectral(op)) {       // passes A and B of the hand-written spectral step (phase_fft.h)
+        float2 *hbuf = reinterpret_cast<float2 *>(resid_c);
+        const float2 *tw = host_of(op)->d_tw;
+        prfft::k_pr_rows_fwd<<<dim3(prfft::IMG / 4, (unsigned)planes), 256, 0, s>>>(
+            f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, hbuf, tw, (int)c, f.k);
+        if ((rc = check_launch()) != DPSX_OK) return rc;
+        const unsigned tiles = (prfft::HS + prfft::CT - 1) / prfft::CT;
+        const size_t lds = (size_t)(prfft::N + prfft::N * prfft::CT) * sizeof(float2);
+        prfft::k_pr_cols<<<dim3(tiles, (unsigned)planes), 256, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
+        return check_launch();
+    }
     if (vec) {      // S1 and the transform's input staging in one pass
         k_phase_s1_pre<<<dim3((sz * (sz / 4) + PT - 1) / PT, (unsigned)planes), PT, 0, s>>>(
             f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, real, h, pad, sz, (int)c, f.k);
@@ -405,6 +442,12 @@ int phase_step_bwd_fused(dpsx_op *op, float *resid_c, const StepBwdArgs &b, hipS
 {
     const int64_t planes = b.n * b.c;
     if (planes == 0) return DPSX_OK;
+    if (spectral(op)) {              // pass C
+        prfft::k_pr_rows_inv<<<dim3(prfft::IMG / 4, (unsigned)planes), 256, 0, s>>>(
+            reinterpret_cast<const float2 *>(resid_c), b.norm, b.inside, b.g_extra, b.scale, b.power, -b.k.b,
+            b.g_model_out, host_of(op)->d_tw, (int)b.c);
+        return check_launch();
+    }
     const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;
     float *real = resid_c;
     float2 *half = reinterpret_cast<float2 *>(reinterpret_cast<char *>(resid_c) +

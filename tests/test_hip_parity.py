@@ -430,6 +430,15 @@ def test_semantic_guidance_fused_matches_per_op(K, golden, oname):
     assert rel_l2(res[0][1], res[1][1]) < 1e-4 and rel_l2(res[0][2], res[1][2]) < 1e-4
 
 
+@pytest.mark.parametrize("t,power,extra", [(700, 1, False), (300, 2, True), (0, 1, False)])
+def test_phase_spectral_step_full_size(K, oracle, t, power, extra):
+    """256 x 256, oversample 2.0 takes the hand-written three-pass spectral step (csrc/phase_fft.h: row FFTs fused with
+    S1, column FFT + pointwise + inverse in LDS, row inverse fused with the gate epilogue) instead of the library
+    transforms: same gates as every other fused step, against the oracle's numpy-free C DFT path."""
+    _fused_case(K, oracle, "phase", 2, 256, t, 0.6, power, seed=40 + t, extra=extra)
+    _fused_case(K, oracle, "phase", 1, 256, t, 0.6, power, seed=41 + t, extra=extra, finalize=True)
+
+
 def test_fused_step_full_size_headline(K, oracle):
     """BASELINE headline geometry (Gaussian deblur, 256 x 256) on a particle subset the oracle finishes fast."""
     _fused_case(K, oracle, "gauss", 2, 256, 500, 0.3, 1, seed=11)

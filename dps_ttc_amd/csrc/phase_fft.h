@@ -21,12 +21,20 @@ namespace prfft {
 
 constexpr int N = 384, HS = 193, IMG = 256, PADW = 64, HALF = 192, CT = 16;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
-__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
+// complex values as 2-vectors: additions are one v_pk_add_f32, products a v_pk_mul_f32 + v_pk_fma_f32 pair
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmul(cf a, cf b)    // a * b
+{
+    return __builtin_elementwise_fma(cf{a.y, a.y}, cf{-b.y, b.x}, cf{a.x, a.x} * b);
+}
+__device__ __forceinline__ cf cmulc(cf a, cf b)   // a * conj(b)
+{
+    return __builtin_elementwise_fma(cf{a.y, a.y}, cf{b.y, b.x}, cf{a.x, a.x} * cf{b.x, -b.y});
+}
+__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
+__device__ __forceinline__ cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+i)
+__device__ __forceinline__ cf ld(const float2 *p) { const float2 v = *p; return cf{v.x, v.y}; }
+__device__ __forceinline__ void st(float2 *p, cf v) { *p = make_float2(v.x, v.y); }
 
 __device__ __forceinline__ int freq_of_pos(int p)
 {
@@ -49,38 +57,39 @@ __device__ __forceinline__ void stage(float2 *d, const float2 *tw, const int L, 
     for (int bf = first; bf < N / R; bf += step) {
         const int blk = bf / sub, j = bf - blk * sub;
         float2 *e = d + (blk * L + j) * STRIDE;
-        float2 v[R];
+        cf v[R];
 #pragma unroll
-        for (int m = 0; m < R; ++m) v[m] = e[m * sub * STRIDE];
+        for (int m = 0; m < R; ++m) v[m] = ld(e + m * sub * STRIDE);
+        const int t1 = tmul * j;       // twiddle W_L^{jq} = tw[t1 * q]; t1 * q < N * (R - 1) / R: no wrap-around
         if constexpr (!FWD) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], tw[(tmul * j * q) % N]);
+            for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], ld(tw + t1 * q));
         }
-        float2 y[R];
+        cf y[R];
         if constexpr (R == 4) {
-            const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]), s13 = cadd(v[1], v[3]), d13 = csub(v[1], v[3]);
-            y[0] = cadd(s02, s13);
-            y[2] = csub(s02, s13);
-            if constexpr (FWD) { y[1] = cadd(d02, mul_mi(d13)); y[3] = cadd(d02, mul_pi(d13)); }
-            else { y[1] = cadd(d02, mul_pi(d13)); y[3] = cadd(d02, mul_mi(d13)); }
+            const cf s02 = v[0] + v[2], d02 = v[0] - v[2], s13 = v[1] + v[3], d13 = v[1] - v[3];
+            y[0] = s02 + s13;
+            y[2] = s02 - s13;
+            if constexpr (FWD) { y[1] = d02 + mul_mi(d13); y[3] = d02 + mul_pi(d13); }
+            else { y[1] = d02 + mul_pi(d13); y[3] = d02 + mul_mi(d13); }
         } else if constexpr (R == 2) {
-            y[0] = cadd(v[0], v[1]);
-            y[1] = csub(v[0], v[1]);
+            y[0] = v[0] + v[1];
+            y[1] = v[0] - v[1];
         } else {   // R == 3: w = exp(-+ 2 pi i / 3) = -1/2 -+ i sqrt(3)/2
-            const float2 s12 = cadd(v[1], v[2]), d12 = csub(v[1], v[2]);
-            const float2 m = make_float2(v[0].x - 0.5f * s12.x, v[0].y - 0.5f * s12.y);
+            const cf s12 = v[1] + v[2], d12 = v[1] - v[2];
+            const cf m = v[0] - 0.5f * s12;
             const float h = 0.86602540378443864676f;
-            const float2 r = FWD ? make_float2(h * d12.y, -h * d12.x) : make_float2(-h * d12.y, h * d12.x);  // -+ i h d12
-            y[0] = cadd(v[0], s12);
-            y[1] = cadd(m, r);
-            y[2] = csub(m, r);
+            const cf r = FWD ? h * mul_mi(d12) : h * mul_pi(d12);      // -+ i h d12
+            y[0] = v[0] + s12;
+            y[1] = m + r;
+            y[2] = m - r;
         }
         if constexpr (FWD) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) y[q] = cmul(y[q], tw[(tmul * j * q) % N]);
+            for (int q = 1; q < R; ++q) y[q] = cmul(y[q], ld(tw + t1 * q));
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) e[q * sub * STRIDE] = y[q];
+        for (int q = 0; q < R; ++q) st(e + q * sub * STRIDE, y[q]);
     }
 }
 
@@ -170,7 +179,15 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
     const bool colok = kx < HS;
     for (int i = threadIdx.x; i < N; i += 256) s_tw[i] = tw_g[i];
     float2 *hp = half + plane * IMG * HS;
-    for (int a = g; a < IMG; a += 256 / CT) s_d[shifted(a) * CT + cl] = colok ? hp[(int64_t)a * HS + kx] : make_float2(0, 0);
+    {
+        constexpr int RPL = IMG / (256 / CT);      // 16 image rows per lane, loads first
+        float2 t[RPL];
+        const int kxc = colok ? kx : HS - 1;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) t[i] = hp[(int64_t)(g + i * (256 / CT)) * HS + kxc];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) s_d[shifted(g + i * (256 / CT)) * CT + cl] = colok ? t[i] : make_float2(0.0f, 0.0f);
+    }
     for (int u = 128 + g; u < 256; u += 256 / CT) s_d[u * CT + cl] = make_float2(0.0f, 0.0f);   // the zero rows
     __syncthreads();
     fft_fwd<CT>(s_d + cl, s_tw, g, 256 / CT);
@@ -184,16 +201,25 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
         int ox = kx + HALF, px = mx + HALF;
         ox = ox >= N ? ox - N : ox;
         px = px >= N ? px - N : px;
-        for (int p = g; p < N; p += 256 / CT) {
-            const int ky = freq_of_pos(p), my = ky == 0 ? 0 : N - ky;
+        constexpr int PER = N / (256 / CT);        // 24 positions per lane: all 48 measurement loads issue first
+        float y1[PER], y2[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int ky = freq_of_pos(g + i * (256 / CT)), my = ky == 0 ? 0 : N - ky;
             int oy = ky + HALF, py = my + HALF;
             oy = oy >= N ? oy - N : oy;
             py = py >= N ? py - N : py;
+            y1[i] = yp[oy * N + ox];
+            y2[i] = yp[py * N + px];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int p = g + i * (256 / CT);
             float2 zz = s_d[p * CT + cl];
             zz.x *= inv;
             zz.y *= inv;
             const float mag = sqrtf(zz.x * zz.x + zz.y * zz.y);
-            const float r1 = yp[oy * N + ox] - mag, r2 = yp[py * N + px] - mag;
+            const float r1 = y1[i] - mag, r2 = y2[i] - mag;
             acc = fmaf(r1, r1, acc);
             if (kx != 0 && kx != HALF) acc = fmaf(r2, r2, acc);
             const float f = mag == 0.0f ? 0.0f : 0.5f * (r1 + r2) / mag;

@@ -36,81 +36,151 @@ __device__ __forceinline__ cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+
 __device__ __forceinline__ cf ld(const float2 *p) { const float2 v = *p; return cf{v.x, v.y}; }
 __device__ __forceinline__ void st(float2 *p, cf v) { *p = make_float2(v.x, v.y); }
 
-__device__ __forceinline__ int freq_of_pos(int p)
-{
-    const int q1 = p / 96, r1 = p - q1 * 96, q2 = r1 / 24, r2 = r1 - q2 * 24, q3 = r2 / 6, r3 = r2 - q3 * 6;
-    const int q4 = r3 / 3, q5 = r3 - q4 * 3;
-    return q1 + 4 * q2 + 16 * q3 + 64 * q4 + 128 * q5;
-}
-__device__ __forceinline__ int pos_of_freq(int k)
-{
-    const int q1 = k & 3, q2 = (k >> 2) & 3, q3 = (k >> 4) & 3, q4 = (k >> 6) & 1, q5 = k >> 7;
-    return q1 * 96 + q2 * 24 + q3 * 6 + q4 * 3 + q5;
-}
+// ---- two-level in-place FFT, 384 = 16 x 24, two LDS passes, the small transforms entirely in registers
+// level 1 (stride 24):  y_q = DFT16_m(x[j + 24 m]) * W_384^(j q)   -> d[j + 24 q]           j in [0, 24)
+// level 2 (blocks)   :  X[q + 16 k'] = DFT24_j'(d[24 q + j'])      -> d[24 q + k']          q in [0, 16)
+// so position p holds frequency p / 24 + 16 (p mod 24).  The inverse is the exact mirror (level 2 first, conjugate
+// twiddles before the inverse DFT16), unnormalised.  W_16 / W_24 / W_6 twiddles are compile-time constants.
+__device__ __forceinline__ int freq_of_pos(int p) { const int q = p / 24; return q + 16 * (p - 24 * q); }
+__device__ __forceinline__ int pos_of_freq(int k) { return 24 * (k & 15) + (k >> 4); }
 
-// One stage over all butterflies bf = first, first + step, ... < N / R of ONE transform whose element p lives at
-// d[p * STRIDE].  FWD: y = DFT_R(x), y_q *= W_L^{jq}.  !FWD: the exact inverse (without the 1/R).
-template <int R, int STRIDE, bool FWD>
-__device__ __forceinline__ void stage(float2 *d, const float2 *tw, const int L, const int first, const int step)
+constexpr float kC16[16] = {1.0f, 0.923879533f, 0.707106781f, 0.382683432f, 6.123234e-17f, -0.382683432f, -0.707106781f, -0.923879533f, -1.0f, -0.923879533f, -0.707106781f, -0.382683432f, -1.8369702e-16f, 0.382683432f, 0.707106781f, 0.923879533f};
+constexpr float kS16[16] = {0.0f, 0.382683432f, 0.707106781f, 0.923879533f, 1.0f, 0.923879533f, 0.707106781f, 0.382683432f, 1.2246468e-16f, -0.382683432f, -0.707106781f, -0.923879533f, -1.0f, -0.923879533f, -0.707106781f, -0.382683432f};
+constexpr float kC24[24] = {1.0f, 0.965925826f, 0.866025404f, 0.707106781f, 0.5f, 0.258819045f, 6.123234e-17f, -0.258819045f, -0.5f, -0.707106781f, -0.866025404f, -0.965925826f, -1.0f, -0.965925826f, -0.866025404f, -0.707106781f, -0.5f, -0.258819045f, -1.8369702e-16f, 0.258819045f, 0.5f, 0.707106781f, 0.866025404f, 0.965925826f};
+constexpr float kS24[24] = {0.0f, 0.258819045f, 0.5f, 0.707106781f, 0.866025404f, 0.965925826f, 1.0f, 0.965925826f, 0.866025404f, 0.707106781f, 0.5f, 0.258819045f, 1.2246468e-16f, -0.258819045f, -0.5f, -0.707106781f, -0.866025404f, -0.965925826f, -1.0f, -0.965925826f, -0.866025404f, -0.707106781f, -0.5f, -0.258819045f};
+constexpr float kC6[6] = {1.0f, 0.5f, -0.5f, -1.0f, -0.5f, 0.5f};
+constexpr float kS6[6] = {0.0f, 0.866025404f, 0.866025404f, 1.2246468e-16f, -0.866025404f, -0.866025404f};
+
+// v * exp(-+ i theta) given cos / sin of theta (FWD: minus)
+template <bool FWD>
+__device__ __forceinline__ cf rot(cf v, float c, float s)
 {
-    const int sub = L / R, tmul = N / L;
-    for (int bf = first; bf < N / R; bf += step) {
-        const int blk = bf / sub, j = bf - blk * sub;
-        float2 *e = d + (blk * L + j) * STRIDE;
-        cf v[R];
+    return FWD ? cmul(v, cf{c, -s}) : cmul(v, cf{c, s});
+}
+template <bool FWD>
+__device__ __forceinline__ void dft2(cf &a, cf &b) { const cf t = a - b; a = a + b; b = t; }
+template <bool FWD>
+__device__ __forceinline__ void dft3(cf &a, cf &b, cf &c)
+{
+    const cf s12 = b + c, d12 = b - c, m = a - 0.5f * s12;
+    const float h = 0.86602540378443864676f;
+    const cf r = FWD ? h * mul_mi(d12) : h * mul_pi(d12);
+    a = a + s12; b = m + r; c = m - r;
+}
+template <bool FWD>
+__device__ __forceinline__ void dft4(cf &a, cf &b, cf &c, cf &d)
+{
+    const cf s02 = a + c, d02 = a - c, s13 = b + d, d13 = b - d;
+    a = s02 + s13; c = s02 - s13;
+    if (FWD) { b = d02 + mul_mi(d13); d = d02 + mul_pi(d13); }
+    else { b = d02 + mul_pi(d13); d = d02 + mul_mi(d13); }
+}
+// natural order in, natural order out
+template <bool FWD>
+__device__ __forceinline__ void dft6(cf (&x)[6])
+{
+    // m = a + 2 b, q = 3 c + d:  X[3c + d] = sum_a W_6^(a d) W_2^(a c) sum_b x[a + 2b] W_3^(b d)
+    cf e0 = x[0], e1 = x[2], e2 = x[4], o0 = x[1], o1 = x[3], o2 = x[5];
+    dft3<FWD>(e0, e1, e2);
+    dft3<FWD>(o0, o1, o2);
+    o1 = rot<FWD>(o1, kC6[1], kS6[1]);
+    o2 = rot<FWD>(o2, kC6[2], kS6[2]);
+    x[0] = e0 + o0; x[3] = e0 - o0;
+    x[1] = e1 + o1; x[4] = e1 - o1;
+    x[2] = e2 + o2; x[5] = e2 - o2;
+}
+template <bool FWD>
+__device__ __forceinline__ void dft16(cf (&x)[16])
+{
+    // m = m1 + 4 m2, q = 4 q1 + q2:  X[4 q1 + q2] = sum_m1 W_16^(m1 q2) W_4^(m1 q1) sum_m2 x[m1 + 4 m2] W_4^(m2 q2)
 #pragma unroll
-        for (int m = 0; m < R; ++m) v[m] = ld(e + m * sub * STRIDE);
-        const int t1 = tmul * j;       // twiddle W_L^{jq} = tw[t1 * q]; t1 * q < N * (R - 1) / R: no wrap-around
-        if constexpr (!FWD) {
+    for (int m1 = 0; m1 < 4; ++m1) dft4<FWD>(x[m1], x[m1 + 4], x[m1 + 8], x[m1 + 12]);    // x[m1 + 4 q2] = A[m1][q2]
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], ld(tw + t1 * q));
-        }
-        cf y[R];
-        if constexpr (R == 4) {
-            const cf s02 = v[0] + v[2], d02 = v[0] - v[2], s13 = v[1] + v[3], d13 = v[1] - v[3];
-            y[0] = s02 + s13;
-            y[2] = s02 - s13;
-            if constexpr (FWD) { y[1] = d02 + mul_mi(d13); y[3] = d02 + mul_pi(d13); }
-            else { y[1] = d02 + mul_pi(d13); y[3] = d02 + mul_mi(d13); }
-        } else if constexpr (R == 2) {
-            y[0] = v[0] + v[1];
-            y[1] = v[0] - v[1];
-        } else {   // R == 3: w = exp(-+ 2 pi i / 3) = -1/2 -+ i sqrt(3)/2
-            const cf s12 = v[1] + v[2], d12 = v[1] - v[2];
-            const cf m = v[0] - 0.5f * s12;
-            const float h = 0.86602540378443864676f;
-            const cf r = FWD ? h * mul_mi(d12) : h * mul_pi(d12);      // -+ i h d12
-            y[0] = v[0] + s12;
-            y[1] = m + r;
-            y[2] = m - r;
-        }
-        if constexpr (FWD) {
+    for (int m1 = 1; m1 < 4; ++m1)
 #pragma unroll
-            for (int q = 1; q < R; ++q) y[q] = cmul(y[q], ld(tw + t1 * q));
-        }
+        for (int q2 = 1; q2 < 4; ++q2) x[m1 + 4 * q2] = rot<FWD>(x[m1 + 4 * q2], kC16[m1 * q2], kS16[m1 * q2]);
+    cf y[16];
 #pragma unroll
-        for (int q = 0; q < R; ++q) st(e + q * sub * STRIDE, y[q]);
+    for (int q2 = 0; q2 < 4; ++q2) {
+        cf t0 = x[0 + 4 * q2], t1 = x[1 + 4 * q2], t2 = x[2 + 4 * q2], t3 = x[3 + 4 * q2];
+        dft4<FWD>(t0, t1, t2, t3);                                                      // index q1
+        y[q2] = t0; y[4 + q2] = t1; y[8 + q2] = t2; y[12 + q2] = t3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = y[i];
+}
+template <bool FWD>
+__device__ __forceinline__ void dft24(cf (&x)[24])
+{
+    // m = m1 + 4 m2 (m2 < 6), q = 6 q1 + q2 (q2 < 6):
+    // X[6 q1 + q2] = sum_m1 W_24^(m1 q2) W_4^(m1 q1) sum_m2 x[m1 + 4 m2] W_6^(m2 q2)
+    cf B[4][6];
+#pragma unroll
+    for (int m1 = 0; m1 < 4; ++m1) {
+        cf t[6];
+#pragma unroll
+        for (int m2 = 0; m2 < 6; ++m2) t[m2] = x[m1 + 4 * m2];
+        dft6<FWD>(t);
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) B[m1][q2] = (m1 == 0 || q2 == 0) ? t[q2] : rot<FWD>(t[q2], kC24[m1 * q2], kS24[m1 * q2]);
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < 6; ++q2) {
+        cf t0 = B[0][q2], t1 = B[1][q2], t2 = B[2][q2], t3 = B[3][q2];
+        dft4<FWD>(t0, t1, t2, t3);
+        x[q2] = t0; x[6 + q2] = t1; x[12 + q2] = t2; x[18 + q2] = t3;
     }
 }
 
-// all threads of the block call these together (block-wide barriers between stages)
+// element p of the transform lives at d[p * STRIDE]; `first`, `step`: this lane's share of the 24 level-1 butterflies
+// and of the 16 level-2 blocks.  All threads of the block call these together.
 template <int STRIDE>
 __device__ __forceinline__ void fft_fwd(float2 *d, const float2 *tw, int first, int step)
 {
-    stage<4, STRIDE, true>(d, tw, 384, first, step); __syncthreads();
-    stage<4, STRIDE, true>(d, tw, 96, first, step);  __syncthreads();
-    stage<4, STRIDE, true>(d, tw, 24, first, step);  __syncthreads();
-    stage<2, STRIDE, true>(d, tw, 6, first, step);   __syncthreads();
-    stage<3, STRIDE, true>(d, tw, 3, first, step);   __syncthreads();
+    for (int j = first; j < 24; j += step) {
+        cf x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = ld(d + (j + 24 * m) * STRIDE);
+        dft16<true>(x);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], ld(tw + j * q));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) st(d + (j + 24 * q) * STRIDE, x[q]);
+    }
+    __syncthreads();
+    for (int q = first; q < 16; q += step) {
+        cf x[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) x[j] = ld(d + (24 * q + j) * STRIDE);
+        dft24<true>(x);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) st(d + (24 * q + k) * STRIDE, x[k]);
+    }
+    __syncthreads();
 }
 template <int STRIDE>
 __device__ __forceinline__ void fft_inv(float2 *d, const float2 *tw, int first, int step)
 {
-    stage<3, STRIDE, false>(d, tw, 3, first, step);   __syncthreads();
-    stage<2, STRIDE, false>(d, tw, 6, first, step);   __syncthreads();
-    stage<4, STRIDE, false>(d, tw, 24, first, step);  __syncthreads();
-    stage<4, STRIDE, false>(d, tw, 96, first, step);  __syncthreads();
-    stage<4, STRIDE, false>(d, tw, 384, first, step); __syncthreads();
+    for (int q = first; q < 16; q += step) {
+        cf x[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) x[k] = ld(d + (24 * q + k) * STRIDE);
+        dft24<false>(x);
+#pragma unroll
+        for (int j = 0; j < 24; ++j) st(d + (24 * q + j) * STRIDE, x[j]);
+    }
+    __syncthreads();
+    for (int j = first; j < 24; j += step) {
+        cf x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = ld(d + (j + 24 * q) * STRIDE);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmulc(x[q], ld(tw + j * q));
+        dft16<false>(x);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) st(d + (j + 24 * m) * STRIDE, x[m]);
+    }
+    __syncthreads();
 }
 
 // image row a <-> padded, ifftshifted row u;  image column b <-> v   (both: (a + 64 + 192) mod 384)

@@ -406,7 +406,7 @@ int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_
     if (vec && spectral(op)) {       // passes A and B of the hand-written spectral step (phase_fft.h)
         float2 *hbuf = reinterpret_cast<float2 *>(resid_c);
         const float2 *tw = host_of(op)->d_tw;
-        prfft::k_pr_rows_fwd<<<dim3(prfft::IMG / 4, (unsigned)planes), 256, 0, s>>>(
+        prfft::k_pr_rows_fwd<<<dim3(prfft::IMG / prfft::RPB, (unsigned)planes), 256, 0, s>>>(
             f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, hbuf, tw, (int)c, f.k);
         if ((rc = check_launch()) != DPSX_OK) return rc;
         const unsigned tiles = (prfft::HS + prfft::CT - 1) / prfft::CT;
@@ -443,7 +443,7 @@ int phase_step_bwd_fused(dpsx_op *op, float *resid_c, const StepBwdArgs &b, hipS
     const int64_t planes = b.n * b.c;
     if (planes == 0) return DPSX_OK;
     if (spectral(op)) {              // pass C
-        prfft::k_pr_rows_inv<<<dim3(prfft::IMG / 4, (unsigned)planes), 256, 0, s>>>(
+        prfft::k_pr_rows_inv<<<dim3(prfft::IMG / prfft::RPB, (unsigned)planes), 256, 0, s>>>(
             reinterpret_cast<const float2 *>(resid_c), b.norm, b.inside, b.g_extra, b.scale, b.power, -b.k.b,
             b.g_model_out, host_of(op)->d_tw, (int)b.c);
         return check_launch();

@@ -186,7 +186,9 @@ __device__ __forceinline__ void fft_inv(float2 *d, const float2 *tw, int first, 
 // image row a <-> padded, ifftshifted row u;  image column b <-> v   (both: (a + 64 + 192) mod 384)
 __device__ __forceinline__ int shifted(int a) { const int u = a + PADW + HALF; return u >= N ? u - N : u; }
 
-// ---- pass A: 4 image rows per block (one per wave); half: [planes][256][193]
+// ---- pass A: RPW image rows per wave (64 / RPW lanes each), 4 waves per block; half: [planes][256][193]
+constexpr int RPW = 2, RPB = 4 * RPW, LPR = 64 / RPW;       // rows per wave / per block, lanes per row
+
 __global__ __launch_bounds__(256) void k_pr_rows_fwd(const float *__restrict__ x, const float *__restrict__ mo,
                                                      const float *__restrict__ z, float *__restrict__ x0o,
                                                      float *__restrict__ so, uint8_t *__restrict__ ins,
@@ -194,46 +196,58 @@ __global__ __launch_bounds__(256) void k_pr_rows_fwd(const float *__restrict__ x
                                                      int c, dpsx::Coefs k)
 {
     __shared__ float2 s_tw[N];
-    __shared__ float2 s_row[4][N];
+    __shared__ float2 s_row[RPB][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t plane = blockIdx.y;
-    const int a = blockIdx.x * 4 + wave;                 // image row
+    const int a0 = blockIdx.x * RPB + wave * RPW;        // first image row of this wave
     for (int i = threadIdx.x; i < N; i += 256) s_tw[i] = tw_g[i];
-    const int64_t hw = (int64_t)IMG * IMG, o = plane * hw + (int64_t)a * IMG + 4 * lane;
-    const int64_t n = plane / c, ch = plane % c, e = (n * 2 * c + ch) * hw + (int64_t)a * IMG + 4 * lane;
-    const float4 xv = *reinterpret_cast<const float4 *>(x + o);
-    const float4 ev = *reinterpret_cast<const float4 *>(mo + e);
-    float4 vv = make_float4(0, 0, 0, 0), zv = vv;
-    if (k.add_noise & 1) {
-        vv = *reinterpret_cast<const float4 *>(mo + e + (int64_t)c * hw);
-        zv = *reinterpret_cast<const float4 *>(z + o);
+    const int64_t hw = (int64_t)IMG * IMG;
+    const int64_t n = plane / c, ch = plane % c;
+    float4 xv[RPW], ev[RPW], vv[RPW], zv[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {                      // one float4 unit of each of the wave's rows per lane
+        const int64_t o = plane * hw + (int64_t)(a0 + r) * IMG + 4 * lane;
+        const int64_t e = (n * 2 * c + ch) * hw + (int64_t)(a0 + r) * IMG + 4 * lane;
+        xv[r] = *reinterpret_cast<const float4 *>(x + o);
+        ev[r] = *reinterpret_cast<const float4 *>(mo + e);
+        vv[r] = zv[r] = make_float4(0, 0, 0, 0);
+        if (k.add_noise & 1) {
+            vv[r] = *reinterpret_cast<const float4 *>(mo + e + (int64_t)c * hw);
+            zv[r] = *reinterpret_cast<const float4 *>(z + o);
+        }
     }
-    bool b0, b1, b2, b3;
-    float4 x0, sm;
-    x0.x = dpsx::post_x0(xv.x, ev.x, k, b0);
-    x0.y = dpsx::post_x0(xv.y, ev.y, k, b1);
-    x0.z = dpsx::post_x0(xv.z, ev.z, k, b2);
-    x0.w = dpsx::post_x0(xv.w, ev.w, k, b3);
-    sm.x = dpsx::post_sample(xv.x, x0.x, vv.x, zv.x, k);
-    sm.y = dpsx::post_sample(xv.y, x0.y, vv.y, zv.y, k);
-    sm.z = dpsx::post_sample(xv.z, x0.z, vv.z, zv.z, k);
-    sm.w = dpsx::post_sample(xv.w, x0.w, vv.w, zv.w, k);
-    *reinterpret_cast<float4 *>(x0o + o) = x0;
-    *reinterpret_cast<float4 *>(so + o) = sm;
-    *reinterpret_cast<uchar4 *>(ins + o) = make_uchar4(b0, b1, b2, b3);
-    // the padded, shifted row: image columns 4 lane .. 4 lane + 3 sit at v0 .. v0 + 3; columns 128..255 of v are zero
-    float2 *row = s_row[wave];
     const int v0 = shifted(4 * lane);
-    row[v0] = make_float2(x0.x, 0.0f);
-    row[v0 + 1] = make_float2(x0.y, 0.0f);
-    row[v0 + 2] = make_float2(x0.z, 0.0f);
-    row[v0 + 3] = make_float2(x0.w, 0.0f);
-    row[128 + 2 * lane] = make_float2(0.0f, 0.0f);
-    row[129 + 2 * lane] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t o = plane * hw + (int64_t)(a0 + r) * IMG + 4 * lane;
+        bool b0, b1, b2, b3;
+        float4 x0, sm;
+        x0.x = dpsx::post_x0(xv[r].x, ev[r].x, k, b0);
+        x0.y = dpsx::post_x0(xv[r].y, ev[r].y, k, b1);
+        x0.z = dpsx::post_x0(xv[r].z, ev[r].z, k, b2);
+        x0.w = dpsx::post_x0(xv[r].w, ev[r].w, k, b3);
+        sm.x = dpsx::post_sample(xv[r].x, x0.x, vv[r].x, zv[r].x, k);
+        sm.y = dpsx::post_sample(xv[r].y, x0.y, vv[r].y, zv[r].y, k);
+        sm.z = dpsx::post_sample(xv[r].z, x0.z, vv[r].z, zv[r].z, k);
+        sm.w = dpsx::post_sample(xv[r].w, x0.w, vv[r].w, zv[r].w, k);
+        *reinterpret_cast<float4 *>(x0o + o) = x0;
+        *reinterpret_cast<float4 *>(so + o) = sm;
+        *reinterpret_cast<uchar4 *>(ins + o) = make_uchar4(b0, b1, b2, b3);
+        // the padded, shifted row: image columns 4 lane .. + 3 sit at v0 .. v0 + 3; columns 128..255 of v are zero
+        float2 *row = s_row[wave * RPW + r];
+        row[v0] = make_float2(x0.x, 0.0f);
+        row[v0 + 1] = make_float2(x0.y, 0.0f);
+        row[v0 + 2] = make_float2(x0.z, 0.0f);
+        row[v0 + 3] = make_float2(x0.w, 0.0f);
+        row[128 + 2 * lane] = make_float2(0.0f, 0.0f);
+        row[129 + 2 * lane] = make_float2(0.0f, 0.0f);
+    }
     __syncthreads();
-    fft_fwd<1>(row, s_tw, lane, 64);
-    float2 *out = half + (plane * IMG + a) * HS;
-    for (int kx = lane; kx < HS; kx += 64) out[kx] = row[pos_of_freq(kx)];
+    const int sub = lane / LPR, l = lane - sub * LPR;      // this lane's row within the wave, lane within the row
+    float2 *row = s_row[wave * RPW + sub];
+    fft_fwd<1>(row, s_tw, l, LPR);
+    float2 *out = half + (plane * IMG + a0 + sub) * HS;
+    for (int kx = l; kx < HS; kx += LPR) out[kx] = row[pos_of_freq(kx)];
 }
 
 // ---- pass B: one (plane, 16-column tile) per block
@@ -304,40 +318,48 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
     if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
 }
 
-// ---- pass C: 4 image rows per block
+// ---- pass C: RPW image rows per wave
 __global__ __launch_bounds__(256) void k_pr_rows_inv(const float2 *__restrict__ half, const float *__restrict__ norm,
                                                      const uint8_t *__restrict__ ins, const float *__restrict__ g_extra,
                                                      float scale, int power, float neg_b, float *__restrict__ g_mo,
                                                      const float2 *__restrict__ tw_g, int c)
 {
     __shared__ float2 s_tw[N];
-    __shared__ float2 s_row[4][N];
+    __shared__ float2 s_row[RPB][N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t plane = blockIdx.y;
-    const int a = blockIdx.x * 4 + wave;
+    const int a0 = blockIdx.x * RPB + wave * RPW;
     for (int i = threadIdx.x; i < N; i += 256) s_tw[i] = tw_g[i];
-    float2 *row = s_row[wave];
-    const float2 *in = half + (plane * IMG + a) * HS;
-    for (int kx = lane; kx < HS; kx += 64) {
-        const float2 v = in[kx];
-        row[pos_of_freq(kx)] = v;
-        if (kx != 0 && kx != HALF) row[pos_of_freq(N - kx)] = make_float2(v.x, -v.y);   // Hermitian extension
+    {
+        const int sub = lane / LPR, l = lane - sub * LPR;
+        float2 *row = s_row[wave * RPW + sub];
+        const float2 *in = half + (plane * IMG + a0 + sub) * HS;
+        for (int kx = l; kx < HS; kx += LPR) {
+            const float2 v = in[kx];
+            row[pos_of_freq(kx)] = v;
+            if (kx != 0 && kx != HALF) row[pos_of_freq(N - kx)] = make_float2(v.x, -v.y);   // Hermitian extension
+        }
+        __syncthreads();
+        fft_inv<1>(row, s_tw, l, LPR);
     }
-    __syncthreads();
-    fft_inv<1>(row, s_tw, lane, 64);
-    const int64_t n = plane / c, ch = plane % c, hw = (int64_t)IMG * IMG, o = plane * hw + (int64_t)a * IMG + 4 * lane;
+    const int64_t n = plane / c, ch = plane % c, hw = (int64_t)IMG * IMG;
     const float nv = norm[n];
     const float coef = (power == 2 ? -2.0f * scale : (nv == 0.0f ? 0.0f : -scale / nv)) * (1.0f / (float)N);
     const int v0 = shifted(4 * lane);
-    const uchar4 gate = *reinterpret_cast<const uchar4 *>(ins + o);
-    float4 ex = make_float4(0, 0, 0, 0);
-    if (g_extra) ex = *reinterpret_cast<const float4 *>(g_extra + o);
-    float4 g;
-    g.x = gate.x ? neg_b * (coef * row[v0].x + ex.x) : 0.0f;
-    g.y = gate.y ? neg_b * (coef * row[v0 + 1].x + ex.y) : 0.0f;
-    g.z = gate.z ? neg_b * (coef * row[v0 + 2].x + ex.z) : 0.0f;
-    g.w = gate.w ? neg_b * (coef * row[v0 + 3].x + ex.w) : 0.0f;
-    *reinterpret_cast<float4 *>(g_mo + (n * 2 * c + ch) * hw + (int64_t)a * IMG + 4 * lane) = g;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float2 *row = s_row[wave * RPW + r];
+        const int64_t o = plane * hw + (int64_t)(a0 + r) * IMG + 4 * lane;
+        const uchar4 gate = *reinterpret_cast<const uchar4 *>(ins + o);
+        float4 ex = make_float4(0, 0, 0, 0);
+        if (g_extra) ex = *reinterpret_cast<const float4 *>(g_extra + o);
+        float4 g;
+        g.x = gate.x ? neg_b * (coef * row[v0].x + ex.x) : 0.0f;
+        g.y = gate.y ? neg_b * (coef * row[v0 + 1].x + ex.y) : 0.0f;
+        g.z = gate.z ? neg_b * (coef * row[v0 + 2].x + ex.z) : 0.0f;
+        g.w = gate.w ? neg_b * (coef * row[v0 + 3].x + ex.w) : 0.0f;
+        *reinterpret_cast<float4 *>(g_mo + (n * 2 * c + ch) * hw + (int64_t)(a0 + r) * IMG + 4 * lane) = g;
+    }
 }
 
 }  // namespace prfft

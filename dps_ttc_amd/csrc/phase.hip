@@ -411,7 +411,7 @@ int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_
         if ((rc = check_launch()) != DPSX_OK) return rc;
         const unsigned tiles = (prfft::HS + prfft::CT - 1) / prfft::CT;
         const size_t lds = (size_t)(prfft::N + prfft::N * prfft::CT) * sizeof(float2);
-        prfft::k_pr_cols<<<dim3(tiles, (unsigned)planes), 256, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
+        prfft::k_pr_cols<<<dim3(tiles, (unsigned)planes), prfft::BT, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
         return check_launch();
     }
     if (vec) {      // S1 and the transform's input staging in one pass

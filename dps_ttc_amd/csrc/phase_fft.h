@@ -251,30 +251,32 @@ __global__ __launch_bounds__(256) void k_pr_rows_fwd(const float *__restrict__ x
 }
 
 // ---- pass B: one (plane, 16-column tile) per block
-__global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, const float *__restrict__ y, int y_n, int c,
+constexpr int BT = 512, TPC = BT / CT;      // threads of pass B, threads per column
+
+__global__ __launch_bounds__(BT) void k_pr_cols(float2 *__restrict__ half, const float *__restrict__ y, int y_n, int c,
                                                  float *__restrict__ partials, const float2 *__restrict__ tw_g)
 {
     extern __shared__ __align__(16) float2 s_dyn[];
     float2 *s_tw = s_dyn, *s_d = s_dyn + N;                 // s_d[384][CT]
-    __shared__ float scratch[256 / dpsx::kWave];
+    __shared__ float scratch[BT / dpsx::kWave];
     const int64_t plane = blockIdx.y;
-    const int tile = blockIdx.x, cl = threadIdx.x & (CT - 1), g = threadIdx.x / CT;   // 16 row-lanes g per column
+    const int tile = blockIdx.x, cl = threadIdx.x & (CT - 1), g = threadIdx.x / CT;   // TPC row-lanes g per column
     const int kx = tile * CT + cl;
     const bool colok = kx < HS;
-    for (int i = threadIdx.x; i < N; i += 256) s_tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < N; i += BT) s_tw[i] = tw_g[i];
     float2 *hp = half + plane * IMG * HS;
     {
-        constexpr int RPL = IMG / (256 / CT);      // 16 image rows per lane, loads first
+        constexpr int RPL = IMG / (TPC);      // 16 image rows per lane, loads first
         float2 t[RPL];
         const int kxc = colok ? kx : HS - 1;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) t[i] = hp[(int64_t)(g + i * (256 / CT)) * HS + kxc];
+        for (int i = 0; i < RPL; ++i) t[i] = hp[(int64_t)(g + i * (TPC)) * HS + kxc];
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) s_d[shifted(g + i * (256 / CT)) * CT + cl] = colok ? t[i] : make_float2(0.0f, 0.0f);
+        for (int i = 0; i < RPL; ++i) s_d[shifted(g + i * (TPC)) * CT + cl] = colok ? t[i] : make_float2(0.0f, 0.0f);
     }
-    for (int u = 128 + g; u < 256; u += 256 / CT) s_d[u * CT + cl] = make_float2(0.0f, 0.0f);   // the zero rows
+    for (int u = 128 + g; u < 256; u += TPC) s_d[u * CT + cl] = make_float2(0.0f, 0.0f);   // the zero rows
     __syncthreads();
-    fft_fwd<CT>(s_d + cl, s_tw, g, 256 / CT);
+    fft_fwd<CT>(s_d + cl, s_tw, g, TPC);
     // pointwise on digit-reversed positions
     const int n = (int)(plane / c), ch = (int)(plane % c);
     const float *yp = y + ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * N * N;
@@ -285,11 +287,11 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
         int ox = kx + HALF, px = mx + HALF;
         ox = ox >= N ? ox - N : ox;
         px = px >= N ? px - N : px;
-        constexpr int PER = N / (256 / CT);        // 24 positions per lane: all 48 measurement loads issue first
+        constexpr int PER = N / (TPC);        // 24 positions per lane: all 48 measurement loads issue first
         float y1[PER], y2[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int ky = freq_of_pos(g + i * (256 / CT)), my = ky == 0 ? 0 : N - ky;
+            const int ky = freq_of_pos(g + i * (TPC)), my = ky == 0 ? 0 : N - ky;
             int oy = ky + HALF, py = my + HALF;
             oy = oy >= N ? oy - N : oy;
             py = py >= N ? py - N : py;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int p = g + i * (256 / CT);
+            const int p = g + i * (TPC);
             float2 zz = s_d[p * CT + cl];
             zz.x *= inv;
             zz.y *= inv;
@@ -311,9 +313,9 @@ __global__ __launch_bounds__(256) void k_pr_cols(float2 *__restrict__ half, cons
         }
     }
     __syncthreads();
-    fft_inv<CT>(s_d + cl, s_tw, g, 256 / CT);
+    fft_inv<CT>(s_d + cl, s_tw, g, TPC);
     if (colok)
-        for (int a = g; a < IMG; a += 256 / CT) hp[(int64_t)a * HS + kx] = s_d[shifted(a) * CT + cl];
+        for (int a = g; a < IMG; a += TPC) hp[(int64_t)a * HS + kx] = s_d[shifted(a) * CT + cl];
     const float t = dpsx::block_sum(acc, scratch);
     if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
 }

@@ -134,14 +134,25 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
         op->nnz = (int)w.size();
         int rc = upload_taps(op, dy, dx, w);
         if (rc != DPSX_OK) { dpsx_op_destroy(op); return rc; }
-        // vertical runs of <= 4 taps per kernel column, window kept inside [-reach4, reach4]
+        // per-side halo of the forward tap list (the adjoint swaps top <-> bottom, left <-> right)
+        {
+            int t = 0, b = 0, l = 0, r = 0;
+            for (size_t i = 0; i < w.size(); ++i) {
+                t = std::max(t, -dy[i]); b = std::max(b, dy[i]);
+                l = std::max(l, -dx[i]); r = std::max(r, dx[i]);
+            }
+            if (t + b < 3) b = 3 - t;                                  // a run window spans four rows
+            op->halo_t = t; op->halo_b = b;
+            op->halo_l = (l + 3) / 4 * 4; op->halo_r = (r + 3) / 4 * 4;
+        }
+        // vertical runs of <= 4 taps per kernel column, window kept inside [-halo_t, halo_b]
         std::vector<TapRun> fwd, adj;
         for (int j = 0; j < ks; ++j) {
             int i = 0;
             while (i < ks) {
                 if (kernel_host[i * ks + j] == 0.0f) { ++i; continue; }
                 const int first = i - R;                               // dy of the run's first tap
-                const int dy0 = std::min(first, reach4 - 3);           // shift up so dy0 + 3 <= reach4
+                const int dy0 = std::min(first, op->halo_b - 3);       // shift up so dy0 + 3 <= halo_b (>= -halo_t)
                 TapRun r{};
                 r.dy0 = dy0; r.dx = j - R;
                 for (int q = 0; q < 4; ++q) {

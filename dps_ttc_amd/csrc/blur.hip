@@ -259,6 +259,82 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
 // =====================================================================
 constexpr int GI = 16;  // outputs per thread: GI consecutive rows of one column
 
+// halo of the staged region on each side of the 64 x 64 tile (columns in multiples of 4)
+struct TapGeom {
+    int t, b, l, r;
+};
+
+// Region loader of the tap-list kernels for REGULAR geometry (h, w multiples of the tile; 16-byte aligned planes):
+// float4 units wholly inside or outside the image, every load unconditional (load_unit_reg), four units per lane in
+// flight before any is consumed; interior units do S1 and emit x0_hat / sample / gate (POST), the others only
+// recompute x0_hat; units outside the tile read their v / noise from a block of zeros.
+template <bool POST, bool REFLECT>
+__device__ __forceinline__ void load_region_taps_reg(float *s_in, const int SW, const int RH, const int RWu,
+                                                     const TapGeom g, const int h0, const int w0, const BlurArgs &a,
+                                                     const int plane)
+{
+    const int h = REFLECT ? a.h : a.src_h, w = REFLECT ? a.w : a.src_w, off = REFLECT ? 0 : a.src_off;
+    const unsigned hw = (unsigned)(h * w);
+    const int n = plane / a.c, ch = plane % a.c;
+    const float *src, *eps = nullptr, *vv = nullptr, *zz = nullptr;
+    if constexpr (POST) {
+        src = a.x_t + (int64_t)plane * hw;
+        eps = a.model_out + ((int64_t)n * 2 * a.c + ch) * hw;
+        vv = eps + (int64_t)a.c * hw;
+        zz = a.noise + (int64_t)plane * hw;
+    } else {
+        src = a.x + (int64_t)plane * hw;
+    }
+    constexpr int B = 4;
+    const int total = RH * RWu;
+    const bool noisy = POST && (a.k.add_noise & 1);
+    for (int base = threadIdx.x; base < total; base += NT * B) {
+        float4 xv[B], ev[B], vq[B], zq[B];
+        int rr[B], cu[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int u = min(base + k * NT, total - 1);          // surplus lanes repeat the last unit
+            rr[k] = u / RWu;
+            cu[k] = u - rr[k] * RWu;
+            const int gy = h0 - g.t + rr[k] - off, gx = w0 - g.l + 4 * cu[k] - off;
+            xv[k] = load_unit_reg<REFLECT>(src, gy, gx, h, w);
+            if constexpr (POST) {
+                ev[k] = load_unit_reg<true>(eps, gy, gx, h, w);
+                const bool interior = rr[k] >= g.t && rr[k] < g.t + TH && 4 * cu[k] >= g.l && 4 * cu[k] < g.l + TW;
+                const unsigned o = (unsigned)(gy * w + gx);
+                vq[k] = *reinterpret_cast<const float4 *>((noisy && interior) ? vv + o : g_zero_unit);
+                zq[k] = *reinterpret_cast<const float4 *>((noisy && interior) ? zz + o : g_zero_unit);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (base + k * NT >= total) break;
+            float4 val = xv[k];
+            if constexpr (POST) {
+                bool b0, b1, b2, b3;
+                val.x = post_x0(xv[k].x, ev[k].x, a.k, b0);
+                val.y = post_x0(xv[k].y, ev[k].y, a.k, b1);
+                val.z = post_x0(xv[k].z, ev[k].z, a.k, b2);
+                val.w = post_x0(xv[k].w, ev[k].w, a.k, b3);
+                const bool interior = rr[k] >= g.t && rr[k] < g.t + TH && 4 * cu[k] >= g.l && 4 * cu[k] < g.l + TW;
+                if (interior) {
+                    float4 sm;
+                    sm.x = post_sample(xv[k].x, val.x, vq[k].x, zq[k].x, a.k);
+                    sm.y = post_sample(xv[k].y, val.y, vq[k].y, zq[k].y, a.k);
+                    sm.z = post_sample(xv[k].z, val.z, vq[k].z, zq[k].z, a.k);
+                    sm.w = post_sample(xv[k].w, val.w, vq[k].w, zq[k].w, a.k);
+                    const int64_t o = (int64_t)plane * hw + (unsigned)((h0 - g.t + rr[k]) * w + w0 - g.l + 4 * cu[k]);
+                    *reinterpret_cast<float4 *>(a.x0_hat + o) = val;
+                    *reinterpret_cast<float4 *>(a.sample + o) = sm;
+                    *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
+                }
+            }
+            *reinterpret_cast<float4 *>(s_in + rr[k] * SW + 4 * cu[k]) = val;
+        }
+    }
+}
+
 // acc[i] = sum over the runs of sum_j w[j] * base[(i + dy0 + j) * SW + dx]: the GI + 3 inputs of a run are read once
 // (consecutive lanes -> consecutive LDS words), the run record through wave-uniform scalar loads
 // SWC > 0: the LDS row stride is a compile-time constant, so the GI + 3 reads of a run are one base register plus
@@ -289,26 +365,44 @@ __device__ __forceinline__ void tap_runs(float (&acc)[GI], const float *base, co
     }
 }
 
-constexpr int kTapsSwFull = TW + 2 * kMaxRadius + 4;   // row stride of the RR = 32 image (61 x 61 kernels)
-
 template <bool POST, bool RESID, bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
+__global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
 {
-    const int RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = RW + 4;
     extern __shared__ __align__(16) float lds[];
     float *s_in = lds, *s_red = lds + RH * SW;
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    const bool regular = VEC && a.h % TH == 0 && a.w % TW == 0 && max(g.t, g.b) < a.h && max(g.l, g.r) < a.w;
+    if constexpr (VEC) {
+        if (regular) load_region_taps_reg<POST, true>(s_in, SW, RH, RW / 4, g, h0, w0, a, plane);
+        else load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+    } else {
+        load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+    }
     __syncthreads();
     const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
     float acc[GI];
-    if (RR == kMaxRadius) tap_runs<kTapsSwFull>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
-    else tap_runs<0>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
+    tap_runs<0>(acc, s_in + (r0 + g.t) * SW + col + g.l, SW, a.runs, a.nruns);
     const int ox = w0 + col;
     float ss = 0.0f;
-    if (ox < a.w) {
+    if (RESID && regular) {
+        // full tile: the lane's 16 measurement values are fetched together (one wait), then r = y - A(x0_hat)
+        const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + r0) * a.w + ox);
+        const int n = plane / a.c, ch = plane % a.c;
+        const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + o;
+        float *rp = a.out ? a.out + (int64_t)plane * hw + o : nullptr;
+        float yv[GI];
+#pragma unroll
+        for (int i = 0; i < GI; ++i) yv[i] = yp[(unsigned)(i * a.w)];
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const float r = yv[i] - acc[i];
+            if (rp) rp[(unsigned)(i * a.w)] = r;
+            ss += r * r;
+        }
+    } else if (ox < a.w) {
 #pragma unroll
         for (int i = 0; i < GI; ++i) {
             const int oy = h0 + r0 + i;
@@ -329,20 +423,27 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, int RR)
 //   k_blur_fold       : reflection_pad2d backward, g[i][j] = sum over the <= 3 x 3 padded positions that
 //                       ReflectionPad maps onto (i, j), fused with the clamp gate / -b*coef epilogue of the step.
 template <bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, int RR)
+__global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, TapGeom g)
 {
-    const int RH = TH + 2 * RR, RW = TW + 2 * RR, SW = RW + 4;
+    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = RW + 4;
     extern __shared__ __align__(16) float lds[];
     float *s_in = lds;
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - RR, w0 - RR, h0, w0, a, plane);
+    // the padded domain need not be a multiple of the tile, but the SOURCE plane (zero-extended) decides whether a
+    // unit is wholly inside or outside: src_w and src_off multiples of 4 are enough for the unconditional loader
+    const bool regular = VEC && a.src_w % 4 == 0 && a.src_off % 4 == 0;
+    if constexpr (VEC) {
+        if (regular) load_region_taps_reg<false, false>(s_in, SW, RH, RW / 4, g, h0, w0, a, plane);
+        else load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+    } else {
+        load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+    }
     __syncthreads();
     const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
     float acc[GI];
-    if (RR == kMaxRadius) tap_runs<kTapsSwFull>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);
-    else tap_runs<0>(acc, s_in + (r0 + RR) * SW + col + RR, SW, a.runs, a.nruns);       // a.runs: the adjoint table
+    tap_runs<0>(acc, s_in + (r0 + g.t) * SW + col + g.l, SW, a.runs, a.nruns);          // a.runs: the adjoint table
     const int ox = w0 + col;
     if (ox < a.w) {
 #pragma unroll
@@ -405,7 +506,10 @@ static inline size_t sep_lds_bytes(int rr)
 {
     return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes;
 }
-static inline size_t taps_lds_bytes(int rr) { return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4)) * 4 + kScratchBytes; }
+static inline size_t taps_lds_bytes(const TapGeom &g)
+{
+    return (size_t)((TH + g.t + g.b) * (TW + g.l + g.r + 4)) * 4 + kScratchBytes;
+}
 
 static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int64_t w)
 {
@@ -515,9 +619,10 @@ template <bool POST, bool RESID>
 static int launch_taps_fwd(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t s)
 {
     set_taps(op, a);
-    const size_t lds = taps_lds_bytes(op->radius4);
-    if (vec) DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, true>), grid_blocks(a), lds, s, a, op->radius4);
-    DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, false>), grid_blocks(a), lds, s, a, op->radius4);
+    const TapGeom g{op->halo_t, op->halo_b, op->halo_l, op->halo_r};
+    const size_t lds = taps_lds_bytes(g);
+    if (vec) DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, true>), grid_blocks(a), lds, s, a, g);
+    DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, false>), grid_blocks(a), lds, s, a, g);
 }
 
 int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h, int64_t w)
@@ -541,14 +646,15 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     fill_geometry(c, a.planes, 1, ph, pw);
     c.src_h = a.h; c.src_w = a.w; c.src_off = r4;
     c.runs = static_cast<const TapRun *>(op->d_runs_adj); c.nruns = op->nruns;
-    const size_t lds = taps_lds_bytes(r4);
+    const TapGeom g{op->halo_b, op->halo_t, op->halo_r, op->halo_l};      // negated offsets: the sides swap
+    const size_t lds = taps_lds_bytes(g);
     const bool v2 = vec && aligned16(scratch);
     {
         static bool done_v = false, done_s = false;
         int rc = v2 ? allow_lds(&k_blur_taps_corrT<true>, lds, done_v) : allow_lds(&k_blur_taps_corrT<false>, lds, done_s);
         if (rc != DPSX_OK) return rc;
-        if (v2) hipLaunchKernelGGL(k_blur_taps_corrT<true>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, r4);
-        else hipLaunchKernelGGL(k_blur_taps_corrT<false>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, r4);
+        if (v2) hipLaunchKernelGGL(k_blur_taps_corrT<true>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, g);
+        else hipLaunchKernelGGL(k_blur_taps_corrT<false>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, g);
         if ((rc = check_launch()) != DPSX_OK) return rc;
     }
     // 2. fold + epilogue

@@ -183,6 +183,9 @@ struct dpsx_op {
     // the same taps as vertical runs of <= 4 (TapRun records): what the tap-list kernels iterate over
     void *d_runs_fwd = nullptr, *d_runs_adj = nullptr;
     int nruns = 0;
+    // halo the tap list actually needs on each side of a tile (rows as they are, columns rounded up to 4): a motion
+    // path usually leaves the centre in one direction, so this is about half of radius4 per axis
+    int halo_t = 0, halo_b = 0, halo_l = 0, halo_r = 0;
     // ---- resize
     int64_t in_h = 0, in_w = 0, out_h = 0, out_w = 0, taps_h = 0, taps_w = 0;
     float *d_w_h = nullptr;  // resize.hip keeps its table owner (ResizeHost*) here

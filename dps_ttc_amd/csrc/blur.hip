@@ -498,6 +498,63 @@ __global__ __launch_bounds__(NT) void k_blur_fold(FoldArgs f)
         f.g[(int64_t)plane * hw + o] = acc;
 }
 
+// four consecutive pixels of a row per lane (w, pw, off multiples of 4; 16-byte aligned planes): the main term and the
+// row folds are float4 loads, only the columns within `reach` of the left / right edge add scalar loads.  Per pixel the
+// terms are added in the order of k_blur_fold (rows outer, columns inner): bit-identical results.
+template <bool EPI>
+__global__ __launch_bounds__(NT) void k_blur_fold4(FoldArgs f)
+{
+    __shared__ float s_nrm[1];
+    const int plane = blockIdx.y, n = plane / f.c, ch = plane % f.c;
+    float coef = 0.0f;
+    if constexpr (EPI) {
+        if (!f.norm_in) {
+            particle_norm_to_lds(f.norm_partials, f.norm_parts, n, s_nrm);
+            __syncthreads();
+        }
+        const float nv = f.norm_in ? f.norm_in[n] : s_nrm[0];
+        coef = norm_coef_dev(nv, f.scale, f.power);
+        if (!f.norm_in && f.norm_out && blockIdx.x == 0 && threadIdx.x == 0 && ch == 0) f.norm_out[n] = nv;
+    }
+    const int unit = blockIdx.x * NT + threadIdx.x, wu = f.w / 4;
+    if (unit >= f.h * wu) return;
+    const int i = unit / wu, j0 = (unit - i * wu) * 4;
+    int sy[2];
+    const int ny = fold_sources(i, f.h, f.reach, sy);
+    const int ps[3] = {i, sy[0], sy[1]};
+    const float *vp = f.v + (int64_t)plane * f.ph * f.pw;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool edge = j0 <= f.reach || j0 + 3 >= f.w - 1 - f.reach;     // some column of the unit has column folds
+    for (int a = 0; a <= ny; ++a) {
+        const float *row = vp + (int64_t)(ps[a] + f.off) * f.pw + f.off;
+        const float4 m = *reinterpret_cast<const float4 *>(row + j0);
+        const float mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += mv[e];
+            if (edge) {
+                int sx[2];
+                const int nx = fold_sources(j0 + e, f.w, f.reach, sx);
+                for (int b = 0; b < nx; ++b) acc[e] += row[sx[b]];
+            }
+        }
+    }
+    const int64_t hw = (int64_t)f.h * f.w, o = (int64_t)i * f.w + j0;
+    if constexpr (EPI) {
+        const uchar4 in = *reinterpret_cast<const uchar4 *>(f.inside + (int64_t)plane * hw + o);
+        float4 ex = make_float4(0, 0, 0, 0);
+        if (f.g_extra) ex = *reinterpret_cast<const float4 *>(f.g_extra + (int64_t)plane * hw + o);
+        float4 g;
+        g.x = in.x ? f.neg_b * (coef * acc[0] + ex.x) : 0.0f;
+        g.y = in.y ? f.neg_b * (coef * acc[1] + ex.y) : 0.0f;
+        g.z = in.z ? f.neg_b * (coef * acc[2] + ex.z) : 0.0f;
+        g.w = in.w ? f.neg_b * (coef * acc[3] + ex.w) : 0.0f;
+        *reinterpret_cast<float4 *>(f.g_model_out + ((int64_t)n * 2 * f.c + ch) * hw + o) = g;
+    } else {
+        *reinterpret_cast<float4 *>(f.g + (int64_t)plane * hw + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // =====================================================================
 // host dispatch
 // =====================================================================
@@ -663,6 +720,13 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     f.norm_out = a.norm_out; f.inside = a.inside_r; f.g_extra = a.g_extra; f.g_model_out = a.g_model_out; f.scale = a.scale;
     f.neg_b = -a.k.b; f.power = a.power; f.c = a.c; f.h = a.h; f.w = a.w; f.ph = ph; f.pw = pw; f.off = r4;
     f.reach = op->reach;
+    const bool vec4 = v2 && a.w % 4 == 0 && pw % 4 == 0 && r4 % 4 == 0 && aligned16(EPI ? (const void *)a.g_model_out : (const void *)a.out) &&
+                      aligned16(a.g_extra) && (reinterpret_cast<uintptr_t>(a.inside_r) & 3u) == 0;
+    if (vec4) {
+        const dim3 grid4((unsigned)((a.h * (a.w / 4) + NT - 1) / NT), (unsigned)a.planes);
+        hipLaunchKernelGGL(k_blur_fold4<EPI>, grid4, dim3(NT), 0, s, f);
+        return check_launch();
+    }
     const dim3 grid((unsigned)((a.h * a.w + NT - 1) / NT), (unsigned)a.planes);
     hipLaunchKernelGGL(k_blur_fold<EPI>, grid, dim3(NT), 0, s, f);
     return check_launch();

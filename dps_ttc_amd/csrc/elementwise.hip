@@ -77,6 +77,7 @@ int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, fl
 // ===================================================================== S1 backward
 // g_pre = [pre in [-1,1]] * (g_x0 + c1 g_s);  g_x = a g_pre + c2 g_s;
 // g_eps = -b g_pre;  g_v = g_s * z * sd * (max_log - min_log) / 4
+template <int U>      // U = 4: one float4 unit per lane (chw % 4 == 0, 16-byte aligned planes); U = 1: scalar
 __global__ __launch_bounds__(kThreads) void k_posterior_bwd(const float *__restrict__ g_x0,
                                                             const float *__restrict__ g_s,
                                                             const float *__restrict__ x,
@@ -86,32 +87,64 @@ __global__ __launch_bounds__(kThreads) void k_posterior_bwd(const float *__restr
                                                             int64_t chw, Coefs k)
 {
     const int64_t p = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * U;
     if (i >= chw) return;
     const int64_t o = p * chw + i, e = p * 2 * chw + i;
-    bool in;
-    (void)post_x0(x[o], mo[e], k, in);
-    const float gs = g_s ? g_s[o] : 0.0f;
+    float xv[U], ev[U], vv[U], zv[U], g0v[U], gsv[U], ox[U], oe[U], ov[U];
+    const bool noisy = k.add_noise == 1 && g_s;
+    if constexpr (U == 4) {
+        auto ld4 = [](const float *q, float (&d)[U]) {
+            const float4 t = *reinterpret_cast<const float4 *>(q);
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        };
+        ld4(x + o, xv);
+        ld4(mo + e, ev);
+        if (g_x0) ld4(g_x0 + o, g0v);
+        if (g_s) ld4(g_s + o, gsv);
+        if (noisy) { ld4(mo + e + chw, vv); ld4(z + o, zv); }
+    } else {
+        xv[0] = x[o]; ev[0] = mo[e];
+        if (g_x0) g0v[0] = g_x0[o];
+        if (g_s) gsv[0] = g_s[o];
+        if (noisy) { vv[0] = mo[e + chw]; zv[0] = z[o]; }
+    }
     // d sample / d x0_hat and d sample / d x (direct): DDPM c1, c2;  DDIM c1 - c2 / b, c2 a / b
     const bool ddim = k.add_noise & 2;
     const float ds_dx0 = ddim ? k.c1 - k.c2 / k.b : k.c1, ds_dx = ddim ? k.c2 * k.a / k.b : k.c2;
-    const float g0 = (g_x0 ? g_x0[o] : 0.0f) + ds_dx0 * gs;
-    const float gp = in ? g0 : 0.0f;
-    g_x[o] = k.a * gp + ds_dx * gs;
-    g_mo[e] = -k.b * gp;
-    float gv = 0.0f;
-    if (k.add_noise == 1 && g_s) {
-        const float sd = expf(0.5f * post_logvar(mo[e + chw], k));
-        gv = gs * z[o] * sd * (0.25f * (k.max_log - k.min_log));
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        bool in;
+        (void)post_x0(xv[q], ev[q], k, in);
+        const float gs = g_s ? gsv[q] : 0.0f;
+        const float g0 = (g_x0 ? g0v[q] : 0.0f) + ds_dx0 * gs;
+        const float gp = in ? g0 : 0.0f;
+        ox[q] = k.a * gp + ds_dx * gs;
+        oe[q] = -k.b * gp;
+        ov[q] = 0.0f;
+        if (noisy) {
+            const float sd = expf(0.5f * post_logvar(vv[q], k));
+            ov[q] = gs * zv[q] * sd * (0.25f * (k.max_log - k.min_log));
+        }
     }
-    g_mo[e + chw] = gv;
+    if constexpr (U == 4) {
+        *reinterpret_cast<float4 *>(g_x + o) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+        *reinterpret_cast<float4 *>(g_mo + e) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+        *reinterpret_cast<float4 *>(g_mo + e + chw) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    } else {
+        g_x[o] = ox[0];
+        g_mo[e] = oe[0];
+        g_mo[e + chw] = ov[0];
+    }
 }
 
 int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const float *mo, const float *z,
                   float *g_x, float *g_mo, int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
 {
     if (n == 0 || chw == 0) return DPSX_OK;
-    k_posterior_bwd<<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, g_s, x, mo, z, g_x, g_mo, chw, k);
+    const bool vec = chw % 4 == 0 && aligned16(g_x0) && aligned16(g_s) && aligned16(x) && aligned16(mo) && aligned16(z) &&
+                     aligned16(g_x) && aligned16(g_mo);
+    if (vec) k_posterior_bwd<4><<<grid_for(chw / 4, n), kThreads, 0, s>>>(g_x0, g_s, x, mo, z, g_x, g_mo, chw, k);
+    else k_posterior_bwd<1><<<grid_for(chw, n), kThreads, 0, s>>>(g_x0, g_s, x, mo, z, g_x, g_mo, chw, k);
     return check_launch();
 }
 

@@ -610,10 +610,10 @@ int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, flo
     return finalize_norm(ws.partials, parts, costs, n, s);
 }
 
-int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, void *stream)
+int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, float *val_out_dev, void *stream)
 {
     if (!v || !idx_out_dev || n < 1) return DPSX_EINVAL;
-    return argmin_f32(v, n, idx_out_dev, (hipStream_t)stream);
+    return argmin_f32(v, n, idx_out_dev, val_out_dev, (hipStream_t)stream);
 }
 
 int dpsx_gather_f32(const float *src, const int64_t *ids_dev, float *dst, int64_t n_out, int64_t n_src,

@@ -270,7 +270,7 @@ int step_update(const float *sample, const float *g_mo, const float *g_unet, flo
 int plain_update(const float *sample, const float *ga, const float *gb, float *out, int64_t count, hipStream_t s);
 int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &a, int parts, hipStream_t s);
 int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
-int argmin_f32(const float *v, int64_t n, int64_t *idx, hipStream_t s);
+int argmin_f32(const float *v, int64_t n, int64_t *idx, float *val, hipStream_t s);
 int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
                bool replicate, hipStream_t s);
 

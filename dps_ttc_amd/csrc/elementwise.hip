@@ -427,7 +427,8 @@ __device__ __forceinline__ bool argmin_better(const ArgMin &a, const ArgMin &b) 
     return a.v < b.v || (a.v == b.v && a.i < b.i);
 }
 
-__global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v, int64_t n, int64_t *__restrict__ out)
+__global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v, int64_t n, int64_t *__restrict__ out,
+                                                     float *__restrict__ val_out)
 {
     __shared__ float s_val[kThreads / kWave];
     __shared__ int64_t s_idx[kThreads / kWave];
@@ -452,12 +453,13 @@ __global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v
             if (argmin_better(c, best)) best = c;
         }
         *out = best.i < 0 ? 0 : best.i;
+        if (val_out) *val_out = best.v;
     }
 }
 
-int argmin_f32(const float *v, int64_t n, int64_t *idx, hipStream_t s)
+int argmin_f32(const float *v, int64_t n, int64_t *idx, float *val, hipStream_t s)
 {
-    k_argmin<<<1, kThreads, 0, s>>>(v, n, idx);
+    k_argmin<<<1, kThreads, 0, s>>>(v, n, idx, val);
     return check_launch();
 }
 
@@ -467,11 +469,17 @@ __global__ __launch_bounds__(kThreads) void k_gather(const float *__restrict__ s
 {
     const int64_t p = blockIdx.y;
     int64_t sidx = replicate ? ids[0] : ids[p];
-    if (sidx < 0 || sidx >= n_src) return;  // never read out of bounds; caller validates ids
-    const float4 *s4 = reinterpret_cast<const float4 *>(src) + sidx * chw4;
     float4 *d4 = reinterpret_cast<float4 *>(dst) + p * chw4;
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i < chw4) d4[i] = s4[i];
+    if (i >= chw4) return;
+    // never read out of bounds: an id outside [0, n_src) poisons its destination particle with NaN (visible in every
+    // later score) instead of faulting -- the ids come from the device (argmin / multinomial), no host check
+    if (sidx < 0 || sidx >= n_src) {
+        const float q = __builtin_nanf("");
+        d4[i] = make_float4(q, q, q, q);
+        return;
+    }
+    d4[i] = (reinterpret_cast<const float4 *>(src) + sidx * chw4)[i];
 }
 
 __global__ __launch_bounds__(kThreads) void k_gather_scalar(const float *__restrict__ src,
@@ -481,9 +489,9 @@ __global__ __launch_bounds__(kThreads) void k_gather_scalar(const float *__restr
 {
     const int64_t p = blockIdx.y;
     int64_t sidx = replicate ? ids[0] : ids[p];
-    if (sidx < 0 || sidx >= n_src) return;
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i < chw) dst[p * chw + i] = src[sidx * chw + i];
+    if (i >= chw) return;
+    dst[p * chw + i] = (sidx < 0 || sidx >= n_src) ? __builtin_nanf("") : src[sidx * chw + i];
 }
 
 int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,

@@ -9,7 +9,13 @@ collective.  The only exchanges are:
   * resampling:  all-gather of scores, identical multinomial draw on every rank from a
                  shared-seed host generator, then an all-gather of particle states.
 `torch.distributed` is plumbing: backend "nccl" is RCCL on ROCm; the CPU tests run the
-same control flow over "gloo".
+same control flow over "gloo".  (SURVEY 8b sketched four `dpsx_comm_*` C symbols wrapping
+RCCL; the host side of this path is Python, which already owns the process group, the
+streams and the tensors, so a second communicator inside libdpsx would only duplicate
+the rendezvous -- the collectives stay here, the kernels stay in the library.)
+
+Global particle order is rank-major: rank r's particles follow rank r-1's.  Shards may be
+unequal or empty (`counts`); every rank must enter every function below.
 """
 import torch
 import torch.distributed as dist
@@ -31,15 +37,49 @@ def shard_range(n_total, rank=None, world=None):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_scores(scores_local):
-    """[n_local] -> [world * n_local] on every rank (equal shards), via ncclAllGather/RCCL."""
+def shard_counts(n_total, world=None):
+    """[particles owned by rank r for r in range(world)] -- what every rank can compute without talking."""
+    world = _world()[1] if world is None else world
+    return [hi - lo for lo, hi in (shard_range(n_total, r, world) for r in range(world))]
+
+
+def exchange_counts(n_local, device):
+    """Shard sizes of all ranks when they cannot be derived (one tiny all-gather + one host read)."""
+    rank, world = _world()
+    if world == 1:
+        return [int(n_local)]
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(v) for v in out.tolist()]
+
+
+def gather_scores(scores_local, counts=None):
+    """[n_local] -> [sum(counts)] on every rank, rank-major, via ncclAllGather / RCCL.
+
+    counts: per-rank shard sizes.  None = exchange them first (robust default, one host read);
+    pass `shard_counts(...)` or `[n] * world` when they are known by construction (no sync).
+    Unequal shards are padded with +inf to the largest one for the collective and compacted after."""
     rank, world = _world()
     scores_local = scores_local.contiguous()
     if world == 1:
         return scores_local
-    out = torch.empty(world * scores_local.numel(), dtype=scores_local.dtype, device=scores_local.device)
-    dist.all_gather_into_tensor(out, scores_local)
-    return out
+    if counts is None:
+        counts = exchange_counts(scores_local.numel(), scores_local.device)
+    if len(counts) != world or counts[rank] != scores_local.numel():
+        raise ValueError(f"shard sizes {counts} do not describe rank {rank}'s {scores_local.numel()} scores")
+    width = max(counts)
+    if width == 0:
+        return scores_local
+    if min(counts) == width:
+        out = torch.empty(world * width, dtype=scores_local.dtype, device=scores_local.device)
+        dist.all_gather_into_tensor(out, scores_local)
+        return out
+    padded = torch.full((width,), float("inf"), dtype=scores_local.dtype, device=scores_local.device)
+    padded[:scores_local.numel()] = scores_local
+    out = torch.empty(world * width, dtype=scores_local.dtype, device=scores_local.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)])
 
 
 def first_argmin(scores):
@@ -49,58 +89,116 @@ def first_argmin(scores):
     return torch.argmin(scores)
 
 
-def global_best_of_n(scores_local, particles_local):
+def locate(index, counts):
+    """global rank-major particle index -> (owner rank, local index)"""
+    for r, c in enumerate(counts):
+        if index < c:
+            return r, index
+        index -= c
+    raise IndexError("particle index beyond the sharded set")
+
+
+def global_best_of_n(scores_local, particles_local, counts=None):
     """Final best-of-N over all ranks' particles (best_of_n_simple.py:32-40 moved on device).
 
-    Returns (winner [1,C,H,W] on every rank, global index, all scores).  The index is read on
-    the host once per trajectory (end of the 1000-step loop), not per step."""
+    Returns (winner [1,C,H,W] on every rank, global rank-major index, all scores).  The index is read on
+    the host once per trajectory (end of the 1000-step loop), not per step.  A rank may hold no particles
+    (`particles_local` of shape [0, C, H, W]): it still enters the collectives and receives the winner."""
     rank, world = _world()
-    all_scores = gather_scores(scores_local)
+    if counts is None:
+        counts = exchange_counts(scores_local.numel(), scores_local.device)
+    all_scores = gather_scores(scores_local, counts)
+    if all_scores.numel() == 0:
+        raise ValueError("best-of-N over an empty particle set")
     best = int(first_argmin(all_scores))
-    n_local = scores_local.numel()
-    owner, local = divmod(best, n_local)
-    winner = particles_local[local:local + 1].contiguous() if owner == rank \
-        else torch.empty_like(particles_local[:1]).contiguous()
+    owner, local = locate(best, counts)
+    if owner == rank:
+        winner = particles_local[local:local + 1].contiguous()
+    else:
+        winner = torch.empty((1,) + tuple(particles_local.shape[1:]), dtype=particles_local.dtype,
+                             device=particles_local.device)
     if world > 1:
         dist.broadcast(winner, src=owner)
     return winner, best, all_scores
 
 
+def global_best_of_n_device(scores_local, particles_local, counts):
+    """The same select without any host read (for timed regions / graph-friendly callers): every rank contributes its
+    local champion, the winner is picked on the device.  -> (winner [1,C,H,W] on every rank, global rank-major index
+    as a device int64 scalar).  Two collectives: [2] floats per rank (min, local index -- exact below 2^24) and one
+    particle per rank (786 KB at 3x256x256) over the direct xGMI links.
+    An empty shard contributes +inf (if every real score is +inf too, an empty lower rank's placeholder could win --
+    torch.argmin's all-inf answer is not reproduced in that corner)."""
+    rank, world = _world()
+    n_local = scores_local.numel()
+    dev, shape = particles_local.device, tuple(particles_local.shape[1:])
+    if n_local == 0:
+        local_best = torch.zeros((), dtype=torch.int64, device=dev)
+        local_min = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
+        champ = torch.zeros((1,) + shape, dtype=particles_local.dtype, device=dev)
+    elif particles_local.is_cuda:
+        local_best, local_min = kernels.argmin(scores_local, want_value=True)
+        champ = kernels.replicate(particles_local, local_best, n_out=1)
+    else:
+        local_best = torch.argmin(scores_local)
+        local_min = scores_local[local_best].reshape(1).float()
+        champ = particles_local[local_best].unsqueeze(0).contiguous()
+    if world == 1:
+        return champ, local_best
+    mine = torch.cat([local_min.reshape(1).float(), local_best.reshape(1).float()])
+    table = torch.empty(world * 2, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(table, mine)
+    table = table.reshape(world, 2)
+    stacked = torch.empty((world,) + shape, dtype=champ.dtype, device=dev)
+    dist.all_gather_into_tensor(stacked, champ)
+    win_rank = first_argmin(table[:, 0].contiguous())                    # lowest rank wins ties = first-min rule
+    offsets = torch.tensor([sum(counts[:r]) for r in range(world)], dtype=torch.int64, device=dev)
+    best = (offsets + table[:, 1].long()).gather(0, win_rank.reshape(1)).reshape(())
+    winner = kernels.replicate(stacked, win_rank, n_out=1) if stacked.is_cuda else stacked[int(win_rank)].unsqueeze(0)
+    return winner, best
+
+
 class GlobalSelect:
     """`SearchDDPM.global_select` hook: per-step best-of-N across ranks (gaussian_diffusion.py:626-633
-    of the reference, generalised to a sharded particle set).  No host sync: every rank broadcasts its
-    local champion slot, the winner is picked on the device from the gathered (min, rank) table."""
+    of the reference, generalised to a sharded particle set).  No host sync: every rank contributes its
+    local champion, the winner is picked on the device from the gathered (min, rank) table.
+    Every rank holds at least one particle (the loop runs a batch per rank)."""
 
     def __call__(self, costs_local, particles_local):
         rank, world = _world()
         if world == 1:
             return kernels.replicate(particles_local, kernels.argmin(costs_local))
         n = particles_local.shape[0]
-        local_best = first_argmin(costs_local)
-        champ = particles_local[local_best].unsqueeze(0).contiguous() if not particles_local.is_cuda else \
-            kernels.replicate(particles_local, local_best, n_out=1)
-        mins = gather_scores(costs_local[local_best].reshape(1))          # [world]
-        champs = [torch.empty_like(champ) for _ in range(world)]
-        dist.all_gather(champs, champ)                                    # world x 786 KB over xGMI
+        if particles_local.is_cuda:
+            local_best, local_min = kernels.argmin(costs_local, want_value=True)
+            champ = kernels.replicate(particles_local, local_best, n_out=1)
+        else:
+            local_best = torch.argmin(costs_local)
+            local_min = costs_local[local_best].reshape(1)
+            champ = particles_local[local_best].unsqueeze(0).contiguous()
+        mins = gather_scores(local_min.reshape(1), counts=[1] * world)    # [world]
+        stacked = torch.empty((world,) + tuple(champ.shape[1:]), dtype=champ.dtype, device=champ.device)
+        dist.all_gather_into_tensor(stacked, champ)                       # world x 786 KB over xGMI
         win_rank = first_argmin(mins)                                     # lowest rank wins ties = first-min rule
-        stacked = torch.cat(champs, dim=0)
         if stacked.is_cuda:
             return kernels.replicate(stacked, win_rank, n_out=n)
         return stacked[int(win_rank)].unsqueeze(0).repeat(n, 1, 1, 1)
 
 
-def resample_ids(scores_local, temperature, generator):
+def resample_ids(scores_local, temperature, generator, counts=None, return_scores=False):
     """Identical multinomial ids on every rank from the gathered scores and a shared-seed HOST generator
-    (gaussian_diffusion.py:689-698: w = exp(-d / T), torch.multinomial with replacement)."""
-    all_scores = gather_scores(scores_local).float().cpu()
+    (gaussian_diffusion.py:689-698: w = exp(-d / T), torch.multinomial with replacement).
+    None when all weights are equal (the reference skips the draw, :693)."""
+    all_scores = gather_scores(scores_local, counts).float().cpu()
     w = torch.exp(-all_scores / temperature)
-    if w.max() == w.min():
-        return None
-    return torch.multinomial(w, all_scores.numel(), replacement=True, generator=generator)
+    ids = None if w.max() == w.min() else torch.multinomial(w, all_scores.numel(), replacement=True,
+                                                            generator=generator)
+    return (ids, all_scores) if return_scores else ids
 
 
 def resample_particles(particles_local, ids_global):
-    """Fetch the resampled particle set: all-gather of states, then a HIP gather of this rank's slots."""
+    """Fetch the resampled particle set: all-gather of states, then a HIP gather of this rank's slots
+    (equal shards: every rank runs the same batch size)."""
     rank, world = _world()
     n_local = particles_local.shape[0]
     if world == 1:
@@ -113,3 +211,18 @@ def resample_particles(particles_local, ids_global):
     if pool.is_cuda:
         return kernels.gather(pool, mine)
     return pool[mine]
+
+
+def global_resample(particles_local, scores_local, temperature, generator):
+    """The resampling block of TTC_DDIM.p_sample_loop (gaussian_diffusion.py:685-698) over a sharded particle set:
+    -> (particles_local', scores_local', ids_global or None).  Same ids as one process holding all particles would
+    draw from the same generator state."""
+    rank, world = _world()
+    n_local = particles_local.shape[0]
+    ids, all_scores = resample_ids(scores_local, temperature, generator, counts=[n_local] * world,
+                                   return_scores=True)
+    if ids is None:
+        return particles_local, scores_local, None
+    fetched = resample_particles(particles_local, ids)
+    mine = ids[rank * n_local:(rank + 1) * n_local]
+    return fetched, all_scores[mine].to(scores_local.device), ids

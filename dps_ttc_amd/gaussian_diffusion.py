@@ -246,8 +246,11 @@ class GaussianDiffusion:
             self._bufs = (handle, kernels.StepBuffers(handle, n, c, h, w, x.device))
         return self._bufs[1]
 
-    def dps_step(self, model, x_prev, idx, measurement, method, cond_kw, handle, noise=None):
-        """One fused DPS step at loop index idx.  Returns (x_next, norm[N]) -- device tensors."""
+    def dps_step(self, model, x_prev, idx, measurement, method, cond_kw, handle, noise=None, loop_kw=None):
+        """One fused DPS step at loop index idx.  Returns (x_next, norm[N]) -- device tensors that live in the
+        sampler's persistent step buffers (valid until the next step; the loops clone what they hand out).
+        loop_kw: the keyword arguments the calling loop passes to measurement_cond_fn besides the tensors
+        (base loop: beta_scale, t -- reference :230-236; ttc_ddim: none -- :678-682)."""
         x_prev = x_prev.detach().requires_grad_()
         with torch.enable_grad():
             model_out = self._call_model(model, x_prev, idx)
@@ -261,7 +264,9 @@ class GaussianDiffusion:
         xp = kernels.f32c(x_prev.detach(), "x_t")
         y = kernels.f32c(measurement, "measurement")
         kernels.step_fwd(handle, buf, xp, mo, noise, y, coefs)
-        spec = method.fused_spec(beta_scale=self.betas[idx], t=idx / self.num_timesteps, **cond_kw)
+        if loop_kw is None:
+            loop_kw = {'beta_scale': self.betas[idx], 't': idx / self.num_timesteps}
+        spec = method.fused_spec(**loop_kw, **cond_kw)
         g_sem, self._step_semantic = None, None
         if "semantic" in spec:            # embedder forward + VJP on x0_hat (torch), between the two HIP halves
             g_sem, self._step_semantic = spec["semantic"](buf.x0_hat)
@@ -325,6 +330,10 @@ class GaussianDiffusion:
                 semantic = ret[2] if len(ret) > 2 and returns_gradient else semantic
             if record and idx % 100 == 0:
                 self._record(save_root, kwargs.get('path_curr_group_idx', 0), idx)
+        # the fused step hands back views of the persistent ping-pong / norm buffers, which the next trajectory on
+        # this sampler overwrites: what leaves the loop is a copy (one per 1000-step trajectory)
+        img = img.clone()
+        distance = distance.clone() if torch.is_tensor(distance) else distance
         self.last_measurement_distance, self.last_semantic_distance = distance, semantic
         if ttc_driver_call:
             return img
@@ -468,7 +477,7 @@ class SearchDDPM(DDPM):
             img, costs = self.search_step(model, img, idx, measurement, handle)
             if kwargs.get('trace', False):
                 self.best_costs.append(costs)
-        return img
+        return img.clone()
 
     @torch.no_grad()
     def resample_update(self, candidates, denoised_candidates, operator, measurement, resample=True, rs_temp=0.01,
@@ -502,13 +511,22 @@ class SearchDDPM(DDPM):
 
 @register_sampler(name='ttc_ddim')
 class TTC_DDIM(DDIM):
-    """DDIM + multinomial particle resampling every 10 steps (reference :644-707)."""
+    """DDIM + multinomial particle resampling every 10 steps (reference :644-707).
+
+    Multi-GPU (SURVEY.md 8e iii): with `global_resample` set (the driver does when WORLD_SIZE > 1) the weights of
+    all ranks' particles are all-gathered, every rank draws the same ids from `resample_generator` (a host
+    generator seeded identically on all ranks) and fetches its slots of the resampled set -- the same particle
+    set one process holding all particles would produce from that generator."""
+
+    global_resample = False
+    resample_generator = None
 
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, **kwargs):
         img = x_start.detach()
         kernels.require_cuda(img, "x_start")
         resample_every_steps, resample_scale = 10, 100
         distance = None
+        self.last_resample_ids = None
         # 'ps'-type methods run the three fused launches with the DDIM variant of S1; the rest (e.g. 'mcg', the
         # method whose two return values fit the reference loop's unpacking at :672) go through the per-op path
         plan = self._fusion_plan(measurement_cond_fn, img)
@@ -517,7 +535,9 @@ class TTC_DDIM(DDIM):
                 noise = self._randn(img)
                 if self.rng_parity:
                     self._randn(measurement, self.parity_measurement_stride)      # q_sample's draw (:668)
-                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise)
+                # this loop passes no beta_scale / t to the conditioning method (:678-682): same on both routes
+                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise,
+                                              loop_kw={})
             else:
                 img = img.detach().requires_grad_()
                 out = self.p_sample(x=img, t=torch.tensor([idx], device=img.device), model=model)
@@ -526,14 +546,31 @@ class TTC_DDIM(DDIM):
                                           noisy_measurement=noisy_measurement, x_prev=img,
                                           x_0_hat=out['pred_xstart'])
                 img, distance = ret[0].detach(), ret[1].detach()
-            n = len(distance)
-            if n > 1 and idx % resample_every_steps == 0:
-                weights = torch.exp(-distance / resample_scale)
-                if weights.max() != weights.min():
-                    # the draw is torch.multinomial (host generator in RNG-replay mode), the gather is HIP
-                    ids = torch.multinomial(weights.cpu(), n, replacement=True).to(img.device) if self.rng_parity \
-                        else torch.multinomial(weights, n, replacement=True)
-                    self.last_resample_ids = ids
-                    img = kernels.gather(img, ids)
-                    distance = distance[ids]
-        return img, distance
+            if idx % resample_every_steps == 0:
+                img, distance = self._resample(img, distance, resample_scale)
+        return img.clone(), distance.clone()
+
+    def _resample(self, img, distance, resample_scale):
+        """the resampling block (:685-698): w = exp(-d / 100), multinomial with replacement, skipped when all
+        weights are equal.  The draw is torch.multinomial (RNG parity), the particle gather is HIP."""
+        n = len(distance)
+        if self.global_resample:
+            from . import distributed as dd
+            img, distance, ids = dd.global_resample(img, distance, resample_scale, self.resample_generator)
+            self.last_resample_ids = ids if ids is not None else self.last_resample_ids
+            return img, distance
+        if n <= 1:
+            return img, distance
+        weights = torch.exp(-distance / resample_scale)
+        if self.rng_parity:                      # replay of the reference's host RNG stream (tests)
+            if weights.max() == weights.min():
+                return img, distance
+            ids = torch.multinomial(weights.cpu(), n, replacement=True).to(img.device)
+        else:
+            # no host read: when all weights are equal the draw is replaced by the identity on the device
+            # ([N]-sized glue; an all-zero weight vector must not reach multinomial)
+            flat = weights.max() == weights.min()
+            drawn = torch.multinomial(torch.where(flat, torch.ones_like(weights), weights), n, replacement=True)
+            ids = torch.where(flat, torch.arange(n, device=img.device), drawn)
+        self.last_resample_ids = ids
+        return kernels.gather(img, ids), kernels.gather(distance.reshape(n, 1), ids).reshape(n)

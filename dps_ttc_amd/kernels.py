@@ -271,21 +271,25 @@ def update(sample, g_a, g_b=None):
     return out
 
 
-def argmin(v):
-    """torch.argmin semantics on the device, result stays on the device (int64 scalar tensor)."""
+def argmin(v, want_value=False):
+    """torch.argmin semantics on the device, result stays on the device (int64 scalar tensor).
+    want_value: also return v[argmin] as a [1] fp32 device tensor (no host index, no sync)."""
     v = f32c(v.reshape(-1), "scores")
     if v.numel() == 0:
         raise ValueError("argmin of an empty score vector")
     out = torch.empty((), dtype=torch.int64, device=v.device)
-    check(lib().dpsx_argmin_f32(ptr(v), v.numel(), ptr(out), stream_of(v)), "dpsx_argmin_f32")
-    return out
+    val = torch.empty(1, dtype=torch.float32, device=v.device) if want_value else None
+    check(lib().dpsx_argmin_f32(ptr(v), v.numel(), ptr(out), ptr(val), stream_of(v)), "dpsx_argmin_f32")
+    return (out, val) if want_value else out
 
 
-def gather(src, ids):
-    """src[ids] for an [N, ...] fp32 tensor and int64 ids (gaussian_diffusion.py:697)."""
+def gather(src, ids, validate=False):
+    """src[ids] for an [N, ...] fp32 tensor and int64 ids (gaussian_diffusion.py:697).  No host sync: the kernel
+    never reads out of bounds (a bad id yields a NaN particle); validate=True adds torch's IndexError check
+    (two host reads) for ids that come from outside the package."""
     src = f32c(src)
     ids = ids.to(device=src.device, dtype=torch.int64).contiguous()
-    if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= src.shape[0]):
+    if validate and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= src.shape[0]):
         raise IndexError("gather index out of range")
     dst = torch.empty((ids.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
     chw = src[0].numel() if src.shape[0] else 0

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DPSX_ABI_VERSION 1
+#define DPSX_ABI_VERSION 2
 
 enum {
     DPSX_OK = 0,
@@ -185,9 +185,10 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs,
                    int64_t n, int64_t c, int64_t h, int64_t w,
                    void *workspace, int64_t workspace_bytes, void *stream);
-/* torch.argmin semantics: first minimum wins, NaN counts as the minimum */
-int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, void *stream);
-/* dst[p] = src[ids[p]]   (ids: device int64 [n_out]) */
+/* torch.argmin semantics: first minimum wins, NaN counts as the minimum (gaussian_diffusion.py:631).
+ * val_out_dev (optional, may be NULL) receives v[argmin] -- `costs[best_path]` of :632 without a host index. */
+int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, float *val_out_dev, void *stream);
+/* dst[p] = src[ids[p]]   (ids: device int64 [n_out]; an id outside [0, n_src) fills dst[p] with NaN) */
 int dpsx_gather_f32(const float *src, const int64_t *ids_dev, float *dst,
                     int64_t n_out, int64_t n_src, int64_t chw, void *stream);
 /* dst[p] = src[*idx_dev] for all p  (img[best.repeat(n)], gaussian_diffusion.py:633) */

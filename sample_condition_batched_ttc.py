@@ -13,8 +13,10 @@ measurement distance (best_of_n_simple.py semantics, on device).
 
 Differences from the reference script, all fixes of things that crash there: `--l1` exists,
 the sampler returns a tensor for this call signature, LPIPS is logged only if torchmetrics is installed.
-With `torchrun --nproc-per-node G` the particle groups are sharded over the ranks and the best-of-N pick is global
-(RCCL all-gather of the distances).
+With `torchrun --nproc-per-node G` (the reference shards by hand: run0.sh:12 / run1.sh:13 start one process per GPU
+with its own --path_start_idx) the particle groups are sharded contiguously over the ranks and the best-of-N pick is
+global: RCCL all-gather of the distances, winner broadcast from its owner.  `sampler: search_ddpm` then selects over
+all ranks' particles at every step and `sampler: ttc_ddim` resamples over all of them (SURVEY.md 8e ii-iii).
 """
 import argparse
 import os
@@ -93,9 +95,14 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if world > 1:
         import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", 0))
+        local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("DPSX_DIST_BACKEND", "nccl")      # "nccl" is RCCL; "gloo" only to rehearse on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         args.gpu = local
     if not torch.cuda.is_available():
         raise SystemExit("dps_ttc_amd runs the DPS hot path on an MI355X only (no CPU fallback by design)")
@@ -127,6 +134,17 @@ def main(argv=None):
     logger.info(f"Sampling: {diffusion_config['sampler']} / Steps: {diffusion_config['steps']}")
 
     sampler = create_sampler(**diffusion_config)
+    groups = args.n_paths // args.batch_size
+    if world > 1 and diffusion_config['sampler'] in ('search_ddpm', 'ttc_ddim'):
+        # these loops exchange particles at every select / resample point: every rank runs the same number of groups
+        if groups % world != 0:
+            raise SystemExit(f"sampler {diffusion_config['sampler']} on {world} ranks needs n_paths / batch_size "
+                             f"(= {groups} particle groups) to be a multiple of the number of ranks")
+        if diffusion_config['sampler'] == 'search_ddpm':
+            sampler.global_select = dd.GlobalSelect()
+        else:
+            sampler.global_resample = True
+            sampler.resample_generator = torch.Generator().manual_seed(args.seed or 0)    # same stream on all ranks
     sample_fn = partial(sampler.p_sample_loop, model=model, measurement_cond_fn=measurement_cond_fn,
                         operator=operator, resample_every_steps=args.resample_every_steps,
                         potential_type=args.potential_type, rs_temp=args.rs_temp, anneal_scale=args.anneal_scale,
@@ -151,8 +169,10 @@ def main(argv=None):
     if op_name == 'motion_blur' and rank == 0:
         imsave(os.path.join(out_path, f'kernel_{str(args.kernel_idx).zfill(5)}.png'), clear_color(operator.get_kernel()))
 
-    groups = args.n_paths // args.batch_size
-    my_groups = [g for g in range(groups) if g % world == rank]      # particle groups shard over the ranks
+    # particle groups shard contiguously over the ranks: the rank-major order of the gathered scores is the path order
+    g_lo, g_hi = dd.shard_range(groups, rank, world)
+    my_groups = range(g_lo, g_hi)
+    counts = [c * args.batch_size for c in dd.shard_counts(groups, world)]
     for img_idx, ref_img in enumerate(loader):
         logger.info(f"Inference for image {args.start_idx + img_idx}")
         fname = str(picks[img_idx]).zfill(5)
@@ -185,9 +205,12 @@ def main(argv=None):
         for g in my_groups:
             x_start = torch.randn((args.batch_size, C, H, W), device=device).requires_grad_()
             sample = this_sample_fn(x_start=x_start, measurement=y_n, record=False, save_root=out_path)
+            if isinstance(sample, tuple):       # ttc_ddim hands back (particles, distances) (reference :707)
+                sample = sample[0]
             with torch.no_grad():
-                y_space = operator.forward(sample, **fkw)
-                dist_g = torch.linalg.norm((y_n - y_space).reshape(len(sample), -1), dim=-1)
+                y_space = operator.forward(sample, **fkw)                      # for the PNGs
+                handle = operator.hip_handle_for(fkw['mask']) if op_name == 'inpainting' else operator.hip_handle(sample)
+                dist_g = handle.score(sample, y_n)                             # ||y - A(x_p)||_2 per particle (HIP)
             distances.append(dist_g)
             finals.append(sample)
             for i in range(len(sample)):
@@ -198,10 +221,11 @@ def main(argv=None):
                 imsave(os.path.join(out_path, 'recon_paths', fname, f'path#{path_idx + 1}.png'), clear_color(sample[i].unsqueeze(0)))
                 imsave(os.path.join(out_path, 'recon_paths_y', fname, f'path#{path_idx + 1}_y_space.png'),
                        clear_color(y_space[i].unsqueeze(0)))
-        if not finals:
-            continue
-        # best-of-N over every particle of every rank: argmin of the final measurement distance
-        winner, best, all_d = dd.global_best_of_n(torch.cat(distances), torch.cat(finals))
+        # best-of-N over every particle of every rank: argmin of the final measurement distance.  Every rank enters
+        # (a rank without groups contributes an empty shard and still receives the winner).
+        scores_local = torch.cat(distances) if distances else torch.empty(0, device=device)
+        particles_local = torch.cat(finals) if finals else torch.empty((0, C, H, W), device=device)
+        winner, best, all_d = dd.global_best_of_n(scores_local, particles_local, counts)
         if rank == 0:
             logger.info(f"best-of-{all_d.numel()} = path#{args.path_start_idx + best + 1} | PSNR: "
                         f"{float(compute_psnr(ref_img, winner)):.4f} | distance: {float(all_d[best]):.4f}")

@@ -47,6 +47,44 @@ def _worker(rank, world, port, q):
         fetched = dd.resample_particles(mine_p, ids)
         out["fetch_ok"] = bool(all(torch.equal(fetched[i], particles[ids[rank * n_local + i]]) for i in range(n_local)))
         out["flat"] = dd.resample_ids(torch.ones(3), 100.0, torch.Generator().manual_seed(1)) is None
+        # the sync-free select (what bench.py closes its timed region with): same winner, index as a tensor
+        w2, b2 = dd.global_best_of_n_device(mine_s, mine_p, [3, 3])
+        out["dev_best"] = int(b2)
+        out["dev_winner_ok"] = bool(torch.equal(w2[0], particles[4]))
+        _, tb2 = dd.global_best_of_n_device(tie, mine_p, [3, 3])
+        out["dev_tie_best"] = int(tb2)
+        # --- the driver's layout: n_paths / batch_size = 3 particle groups of 3 on 2 ranks (rank 0: two groups,
+        # rank 1: one), sharded contiguously, so the rank-major index IS the path index
+        groups, batch = 3, 3
+        g_lo, g_hi = dd.shard_range(groups)
+        counts = [c * batch for c in dd.shard_counts(groups)]
+        gen = torch.Generator().manual_seed(5)
+        all_p = torch.randn(groups * batch, 3, 4, 4, generator=gen)
+        all_s = torch.tensor([4.0, 3.0, 8.0, 6.0, 5.0, 9.0, 7.0, 0.5, 2.0])        # winner: path 7 (group 2, rank 1)
+        my_p, my_s = all_p[g_lo * batch:g_hi * batch].clone(), all_s[g_lo * batch:g_hi * batch].clone()
+        wg, bg, ag = dd.global_best_of_n(my_s, my_p, counts)
+        out["groups"] = (counts, bg, ag.tolist(), bool(torch.equal(wg[0], all_p[7])))
+        wg2, bg2 = dd.global_best_of_n_device(my_s, my_p, counts)
+        out["groups_dev"] = (int(bg2), bool(torch.equal(wg2[0], all_p[7])))
+        # counts exchanged instead of derived
+        _, bg3, _ = dd.global_best_of_n(my_s, my_p)
+        out["groups_exchanged"] = bg3
+        # --- fewer groups than ranks: rank 1 holds nothing, still enters the collectives, still gets the winner
+        e_p = all_p[:3].clone() if rank == 0 else torch.empty(0, 3, 4, 4)
+        e_s = torch.tensor([2.0, 1.0, 3.0]) if rank == 0 else torch.empty(0)
+        we, be, ae = dd.global_best_of_n(e_s, e_p, [3, 0])
+        out["empty"] = (be, ae.tolist(), bool(torch.equal(we[0], all_p[1])))
+        we2, be2 = dd.global_best_of_n_device(e_s, e_p, [3, 0])
+        out["empty_dev"] = (int(be2), bool(torch.equal(we2[0], all_p[1])))
+        # --- ttc_ddim's resampling block over the sharded set (control flow only: no kernels on CPU tensors)
+        from dps_ttc_amd.gaussian_diffusion import create_sampler
+        smp = create_sampler(sampler="ttc_ddim", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                             model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                             rescale_timesteps=True, timestep_respacing="20")
+        smp.global_resample, smp.resample_generator = True, torch.Generator().manual_seed(11)
+        d6 = torch.tensor([50.0, 400.0, 30.0, 900.0, 10.0, 250.0])
+        img3, dist3 = smp._resample(particles[lo:hi].clone(), d6[lo:hi].clone(), 100)
+        out["ttc"] = (smp.last_resample_ids.tolist(), img3, dist3.tolist())
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -74,6 +112,28 @@ def test_world_size_2_gloo():
     # same draw as a single process would make from the gathered scores (torch.multinomial, shared seed)
     w = torch.exp(-torch.tensor([5.0, 2.0, 9.0, 2.0, 1.5, 7.0]) / 100.0)
     assert res[0]["ids"] == torch.multinomial(w, 6, replacement=True, generator=torch.Generator().manual_seed(77)).tolist()
+    all_s = [4.0, 3.0, 8.0, 6.0, 5.0, 9.0, 7.0, 0.5, 2.0]
+    for r in (0, 1):
+        assert res[r]["dev_best"] == 4 and res[r]["dev_winner_ok"] and res[r]["dev_tie_best"] == 1
+        # 3 groups on 2 ranks pick the path a single process picks: index 7 = argmin of the concatenated distances
+        assert res[r]["groups"] == ([6, 3], 7, all_s, True) and int(torch.argmin(torch.tensor(all_s))) == 7
+        assert res[r]["groups_dev"] == (7, True) and res[r]["groups_exchanged"] == 7
+        assert res[r]["empty"] == (1, [2.0, 1.0, 3.0], True) and res[r]["empty_dev"] == (1, True)
+    # ttc_ddim: 2 ranks x 3 particles resample to what 1 rank x 6 does with the same generator
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    smp = create_sampler(sampler="ttc_ddim", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="20")
+    smp.global_resample, smp.resample_generator = True, torch.Generator().manual_seed(11)
+    particles = torch.randn(6, 3, 4, 4, generator=torch.Generator().manual_seed(0))
+    d6 = torch.tensor([50.0, 400.0, 30.0, 900.0, 10.0, 250.0])
+    img6, dist6 = smp._resample(particles.clone(), d6.clone(), 100)
+    ids6 = smp.last_resample_ids.tolist()
+    assert len(set(ids6)) > 1
+    for r in (0, 1):
+        ids, img3, dist3 = res[r]["ttc"]
+        assert ids == ids6
+        assert torch.equal(img3, img6[3 * r:3 * r + 3]) and dist3 == dist6[3 * r:3 * r + 3].tolist()
 
 
 def test_single_process_paths():
@@ -83,4 +143,7 @@ def test_single_process_paths():
     assert dd.gather_scores(s) is not None and int(dd.first_argmin(s)) == 1
     w, best, alls = dd.global_best_of_n(s, torch.arange(12.0).reshape(3, 1, 2, 2))
     assert best == 1 and torch.equal(w[0], torch.arange(4.0, 8.0).reshape(1, 2, 2)) and alls.tolist() == s.tolist()
+    w, best = dd.global_best_of_n_device(s, torch.arange(12.0).reshape(3, 1, 2, 2), [3])
+    assert int(best) == 1 and torch.equal(w[0], torch.arange(4.0, 8.0).reshape(1, 2, 2))
+    assert dd.shard_counts(10, 3) == [4, 3, 3] and dd.locate(5, [4, 3, 3]) == (1, 1) and dd.locate(0, [0, 2]) == (1, 0)
     assert int(dd.first_argmin(torch.tensor([2.0, float("nan"), 1.0]))) == 1      # NaN is the minimum (torch.argmin)

@@ -94,3 +94,30 @@ def test_unet_architecture_matches_the_checkpoint_layout():
     m.out[2].weight.data.normal_(0, 0.02)
     (g,) = torch.autograd.grad(m(x, torch.tensor([250.0])).square().sum(), x)
     assert g.shape == x.shape and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def test_reference_import_block_resolves_through_alias_modules():
+    """INTEGRATION.md route A: the import block of the reference driver (sample_condition_batched_ttc.py:11-18)
+    works unchanged with the repo root on sys.path -- `guided_diffusion.*`, `data.dataloader`, `util.*` are the
+    `dps_ttc_amd` modules themselves (shared registries)."""
+    from guided_diffusion.condition_methods import get_conditioning_method
+    from guided_diffusion.measurements import get_noise, get_operator
+    from guided_diffusion.unet import create_model
+    from guided_diffusion.gaussian_diffusion import create_sampler
+    from data.dataloader import get_dataset, get_dataloader
+    from util.img_utils import clear_color, mask_generator
+    from util.logger import get_logger
+    import dps_ttc_amd.condition_methods as cm
+    import dps_ttc_amd.gaussian_diffusion as gd
+    import dps_ttc_amd.measurements as ms
+    import guided_diffusion.measurements as alias
+    assert alias is ms and get_operator is ms.get_operator and get_noise is ms.get_noise
+    assert get_conditioning_method is cm.get_conditioning_method and create_sampler is gd.create_sampler
+    assert callable(create_model) and callable(get_dataset) and callable(get_dataloader)
+    assert callable(clear_color) and callable(mask_generator) and get_logger().name == "DPS"
+    with pytest.raises(NameError):
+        get_operator("no_such_operator", device="cpu")
+    s = create_sampler(sampler="ttc_ddim", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                       model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                       rescale_timesteps=True, timestep_respacing="ddim50")
+    assert s.num_timesteps == 50 and s.global_resample is False

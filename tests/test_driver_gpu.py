@@ -49,3 +49,122 @@ def test_driver_end_to_end(tmp_path, task, sampler):
     assert (root / "best_of_n" / "00000.png").exists()
     d = np.load(root / "00000_pathwise_distances.npy")
     assert d.shape == (2,) and np.isfinite(d).all() and (d > 0).all()
+
+
+def _run_driver(tmp_path, task, sampler, n_paths, batch_size, ranks=1, extra=()):
+    """the driver as its own process(es); ranks > 1: one process per rank on this box's single GPU over gloo
+    (the RCCL path needs one GPU per rank: the driver's round-end multi-GPU run covers it)"""
+    import socket
+    import subprocess
+    tpath, dpath = _setup(tmp_path, task, sampler)
+    out = tmp_path / "results"
+    cmd = [sys.executable, os.path.join(ROOT, "sample_condition_batched_ttc.py"),
+           "--model_config", os.path.join(ROOT, "configs", "model_config.yaml"), "--diffusion_config", dpath,
+           "--task_config", tpath, "--save_dir", str(out), "--n_paths", str(n_paths), "--batch_size", str(batch_size),
+           "--ref_image_idxs", "0", "--timestep_respacing", "3", "--seed", "0", "--gpu", "0", *extra]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(ranks):
+        env = dict(os.environ)
+        if ranks > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), DPSX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    (sub,) = os.listdir(out)
+    return out / sub, logs
+
+
+def _check_best_of_n(root, n_paths):
+    d = np.load(root / "00000_pathwise_distances.npy")
+    assert d.shape == (n_paths,) and np.isfinite(d).all() and (d > 0).all()
+    best = int(np.argmin(d))
+    for i in range(n_paths):
+        assert (root / "recon_paths" / "00000" / f"path#{i + 1}.png").exists(), i
+    # the saved best-of-N image IS the reconstruction of the reported path (not another group's particle)
+    a = open(root / "best_of_n" / "00000.png", "rb").read()
+    b = open(root / "recon_paths" / "00000" / f"path#{best + 1}.png", "rb").read()
+    assert a == b
+    others = [open(root / "recon_paths" / "00000" / f"path#{i + 1}.png", "rb").read() for i in range(n_paths) if i != best]
+    assert all(o != a for o in others)
+    return best
+
+
+def test_driver_more_groups_than_one(tmp_path):
+    """n_paths = 2 x batch_size: the groups' final particles must not alias the sampler's persistent step buffers
+    (every group ends in the same ping-pong slot), so best_of_n/*.png is the image of the reported path."""
+    root, logs = _run_driver(tmp_path, "gaussian_deblur_config.yaml", "ddpm", 4, 2)
+    best = _check_best_of_n(root, 4)
+    assert f"best-of-4 = path#{best + 1} " in logs[0]
+
+
+def test_consecutive_loops_do_not_share_storage():
+    import torch
+    from standin import StandInModel
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    from dps_ttc_amd.measurements import get_noise, get_operator
+    dev = "cuda:0"
+    op = get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device=dev)
+    cm = get_conditioning_method("ps", op, get_noise("gaussian", sigma=0.05), scale=0.3)
+    smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="4")
+    model = StandInModel().to(dev)
+    y = torch.rand(1, 3, 64, 64, device=dev)
+    outs = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        img, d, _ = smp.p_sample_loop(model=model, x_start=torch.randn(2, 3, 64, 64, device=dev).requires_grad_(),
+                                      measurement=y, measurement_cond_fn=cm.conditioning, record=False, save_root=None)
+        outs.append((img, d, img.clone(), d.clone()))
+    assert outs[0][0].data_ptr() != outs[1][0].data_ptr() and outs[0][1].data_ptr() != outs[1][1].data_ptr()
+    assert torch.equal(outs[0][0], outs[0][2]) and torch.equal(outs[0][1], outs[0][3])     # untouched by the 2nd loop
+    assert not torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("sampler,n_paths,batch", [("ddpm", 3, 1), ("search_ddpm", 4, 2), ("ttc_ddim", 4, 2)])
+def test_driver_two_ranks(tmp_path, sampler, n_paths, batch):
+    """two rank processes (gloo rehearsal on one GPU): uneven group shards for the independent-particle loop (3 groups
+    on 2 ranks), per-step global select for search_ddpm, global resampling for ttc_ddim; path numbering is global and
+    the best-of-N image is the reported path's."""
+    task = "gaussian_deblur_config.yaml"
+    root, logs = _run_driver(tmp_path, task, sampler, n_paths, batch, ranks=2)
+    best = _check_best_of_n(root, n_paths) if sampler == "ddpm" else None
+    d = np.load(root / "00000_pathwise_distances.npy")
+    assert d.shape == (n_paths,)
+    assert f"best-of-{n_paths} = path#{int(np.argmin(d)) + 1} " in logs[0]
+    if sampler == "search_ddpm":
+        # every particle of every rank ends as a copy of the global per-step winner: all distances agree
+        assert np.allclose(d, d[0], rtol=1e-6)
+    if best is not None:
+        assert "Path#3 " in logs[1] and "Path#1 " in logs[0] and "Path#2 " in logs[0]
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts the rank processes before any GPU call and
+    relays one JSON line (gloo rehearsal: both ranks share this box's GPU)."""
+    import json
+    import subprocess
+    env = dict(os.environ, DPSX_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--particles", "4", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_particles"] == 8 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and 0 <= rec["best_of_n_index"] < 8 and "roofline" in rec

@@ -316,7 +316,7 @@ def test_residual_norm_and_vjp(K, oracle):
 
 # ----------------------------------------------------------------- fused DPS step vs oracle
 def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask=None, finalize=False, ddim_eta=None,
-                extra=False):
+                extra=False, per_particle_y=False):
     rng = np.random.RandomState(seed)
     sched = oracle.tables.schedule(1000)
     c, ck = coefs_of(K, oracle, t, sched) if ddim_eta is None else ddim_coefs_of(K, oracle, t, ddim_eta, sched)
@@ -329,6 +329,8 @@ def _fused_case(K, oracle, name, n, hw, t, scale, power, seed, kernel=None, mask
     noise = rng.randn(n, 3, hw, hw).astype(np.float32)
     truth = rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32)
     y = orc.forward(truth)
+    if per_particle_y:          # one measurement per particle ([N, ...] instead of the broadcast [1, ...])
+        y = np.repeat(y, n, axis=0)
     y = (y + 0.05 * rng.randn(*y.shape)).astype(np.float32)
     g_unet = (1e-2 * rng.randn(n, 3, hw, hw)).astype(np.float32)
     g_extra = (0.05 * rng.randn(n, 3, hw, hw)).astype(np.float32) if extra else None
@@ -509,13 +511,26 @@ def test_fused_step_is_graph_capturable(K, golden, name, hw):
     assert torch.equal(step(), replayed)       # eager on the new inputs
 
 
-def test_fused_step_full_size_headline(K, oracle):
-    """BASELINE headline geometry (Gaussian deblur, 256 x 256) on a particle subset the oracle finishes fast."""
-    _fused_case(K, oracle, "gauss", 2, 256, 500, 0.3, 1, seed=11)
-    _fused_case(K, oracle, "gauss", 2, 256, 500, 0.3, 2, seed=12, finalize=True)
-    for name in ("sr4", "inpaint", "motion", "phase"):
-        _fused_case(K, oracle, name, 2, 64 if name != "phase" else 32, 300, 0.5, 1, seed=13, finalize=True,
-                    kernel=synthetic_motion_kernel(61, 4), mask=(np.random.RandomState(3).rand(1, 1, 64, 64) < 0.5).astype(np.float32))
+@pytest.mark.parametrize("name", ["gauss", "sr4", "sr8", "inpaint", "motion"])
+@pytest.mark.parametrize("t,power,finalize", [(500, 1, False), (0, 2, True), (500, 2, True), (0, 1, False)])
+def test_fused_step_full_size(K, oracle, name, t, power, finalize):
+    """The launches the BASELINE configs run -- every operator at 256 x 256 (Gaussian 64x64-tile kernel, the wu = 64
+    row-streaming POST,RESID resize kernel for x4 and x8, the 256^2 tap-list and mask kernels) -- against the oracle on
+    a particle subset it finishes fast: both norm-finalisation modes, t in {500, 0}, power in {1, 2}.
+    (reference: resizer.py:55-74, measurements.py:84,108,142,158; phase retrieval at 256^2: test_phase_spectral_step_full_size)"""
+    mask = (np.random.RandomState(3).rand(1, 1, 256, 256) < 0.5).astype(np.float32)
+    _fused_case(K, oracle, name, 2, 256, t, 0.3 if power == 1 else 0.05, power, seed=11 + t + power, finalize=finalize,
+                kernel=synthetic_motion_kernel(61, 4), mask=mask)
+
+
+@pytest.mark.parametrize("name", ["sr4", "sr8", "gauss", "motion", "inpaint"])
+def test_fused_step_full_size_per_particle_measurement(K, oracle, name):
+    """256 x 256 with one measurement per particle (y [N, ...]) against the oracle"""
+    mask = (np.random.RandomState(5).rand(1, 1, 256, 256) < 0.5).astype(np.float32)
+    _fused_case(K, oracle, name, 3, 256, 300, 0.4, 1, seed=77, kernel=synthetic_motion_kernel(61, 6), mask=mask,
+                per_particle_y=True)
+    _fused_case(K, oracle, name, 2, 256, 700, 0.4, 1, seed=78, kernel=synthetic_motion_kernel(61, 6), mask=mask,
+                per_particle_y=True, extra=True, finalize=True)
 
 
 # ----------------------------------------------------------------- conditioning per call (registry API, autograd path)
@@ -623,9 +638,10 @@ def test_ttc_ddim_loop_golden(K, golden, tag, resp, scale):
         return r
     orig = K.gather
 
-    def spy(x, ids):
-        picks.append(ids.cpu().numpy().copy())
-        return orig(x, ids)
+    def spy(x, ids, **kw):
+        if x.dim() == 4:                     # the particle gather (the distances are gathered with the same ids)
+            picks.append(ids.cpu().numpy().copy())
+        return orig(x, ids, **kw)
     K.gather = spy
     try:
         torch.manual_seed(int(g[f"{tag}.rng_seed"]))
@@ -690,9 +706,9 @@ def test_search_ddpm_golden(K, golden, tag, oname):
     best = []
     orig = K.argmin
 
-    def spy(v):
-        r = orig(v)
-        best.append(int(r))
+    def spy(v, **kw):
+        r = orig(v, **kw)
+        best.append(int(r[0] if isinstance(r, tuple) else r))
         return r
     K.argmin = spy
     try:
@@ -754,7 +770,11 @@ def test_argmin_gather_replicate(K, oracle, golden):
     assert K.gather(src4, ids[:0]).shape == (0, 3, 8, 8)
     assert torch.equal(K.replicate(src4, torch.tensor(2, device=DEV)), src4[2:3].repeat(6, 1, 1, 1))
     with pytest.raises(IndexError):
-        K.gather(src4, torch.tensor([6], device=DEV))
+        K.gather(src4, torch.tensor([6], device=DEV), validate=True)
+    bad = K.gather(src4, torch.tensor([1, 6, -1], device=DEV))      # no host check: a bad id poisons its particle only
+    assert torch.equal(bad[0], src4[1]) and bool(torch.isnan(bad[1:]).all())
+    idx, val = K.argmin(v, want_value=True)
+    assert int(idx) == 1 and val.shape == (1,) and float(val) == 1.0
     g = golden("search")
     w = torch.exp(-torch.from_numpy(g["resample.dist"]) / 100.0)
     torch.manual_seed(int(g["resample.seed"]))

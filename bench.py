@@ -120,7 +120,10 @@ def launch_ranks(n):
     if failed:
         sys.stderr.write(out)
         raise SystemExit(f"bench.py: a rank process failed (exit {failed})")
-    sys.stdout.write(out)
+    # stdout carries the ONE JSON line; whatever else a rank's libraries print there (e.g. gloo's connection
+    # banner) goes to stderr
+    for ln in out.splitlines():
+        (sys.stdout if ln.lstrip().startswith('{"metric"') else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
 
 

@@ -14,6 +14,7 @@ SO_PATH = os.environ.get("DPSX_LIB") or os.path.join(_HERE, "lib", "libdpsx.so")
 OK, EINVAL, EUNSUPPORTED, ELAUNCH, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
 KIND_TAPS, KIND_SEP, KIND_RESIZE, KIND_MASK, KIND_IDENT, KIND_PHASE = range(6)
 BLUR_AUTO, BLUR_FORCE_TAPS = 0, 1
+POTENTIALS = {"mean": 1, "min": 2, "diff": 3, "curr": 4}      # DPSX_POT_*
 ABI_VERSION = 2          # DPSX_ABI_VERSION of include/dpsx.h
 
 
@@ -67,6 +68,8 @@ SIGNATURES = {
     "dpsx_step_update_f32": (c_int, [_f, _f, _f, _f, _i64, _i64, POINTER(Coefs), _p]),
     "dpsx_update_f32": (c_int, [_f, _f, _f, _f, _i64, _p]),
     "dpsx_score_f32": (c_int, [c_void_p, _f, _f, _i64, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    "dpsx_score_argmin_f32": (c_int, [c_void_p, _f, _f, _i64, _f, _p, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),
+    "dpsx_resample_cost_f32": (c_int, [c_void_p, _f, _f, _i64, _f, c_int, _f, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "dpsx_argmin_f32": (c_int, [_f, _i64, _p, _f, _p]),
     "dpsx_gather_f32": (c_int, [_f, _p, _f, _i64, _i64, _i64, _p]),
     "dpsx_replicate_f32": (c_int, [_f, _p, _f, _i64, _i64, _i64, _p]),

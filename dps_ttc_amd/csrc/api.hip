@@ -63,6 +63,23 @@ int dpsx_posterior_bwd_f32(const float *g_x0, const float *g_sample, const float
 }
 
 // ------------------------------------------------------------------ operator objects
+// arrival counters of the in-launch reductions (common.h: Tail); zero between launches
+static int alloc_counters(dpsx_op *op)
+{
+    const size_t bytes = (size_t)(1 + kTailMaxParticles) * sizeof(unsigned);
+    DPSX_HIP_TRY(hipMalloc((void **)&op->d_counters, bytes));
+    DPSX_HIP_TRY(hipMemset(op->d_counters, 0, bytes));
+    return DPSX_OK;
+}
+
+static int finish_create(dpsx_op *op, dpsx_op **out)
+{
+    int rc = alloc_counters(op);
+    if (rc != DPSX_OK) { dpsx_op_destroy(op); return rc; }
+    *out = op;
+    return DPSX_OK;
+}
+
 static int upload_taps(dpsx_op *op, const std::vector<int> &dy, const std::vector<int> &dx,
                        const std::vector<float> &w)
 {
@@ -178,8 +195,7 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
             return DPSX_ENOMEM;
         }
     }
-    *out = op;
-    return DPSX_OK;
+    return finish_create(op, out);
 }
 
 int dpsx_op_create_resize(int64_t in_h, int64_t in_w, const float *w_h_host, const int64_t *i_h_host,
@@ -195,8 +211,7 @@ int dpsx_op_create_resize(int64_t in_h, int64_t in_w, const float *w_h_host, con
     op->in_h = in_h; op->in_w = in_w; op->out_h = out_h; op->out_w = out_w; op->taps_h = taps_h; op->taps_w = taps_w;
     int rc = resize_create(op, w_h_host, i_h_host, w_w_host, i_w_host);
     if (rc != DPSX_OK) { delete op; return rc; }
-    *out = op;
-    return DPSX_OK;
+    return finish_create(op, out);
 }
 
 int dpsx_op_create_mask(const float *mask_dev, int64_t h, int64_t w, dpsx_op **out)
@@ -207,8 +222,7 @@ int dpsx_op_create_mask(const float *mask_dev, int64_t h, int64_t w, dpsx_op **o
     op->kind = OP_MASK;
     op->mask = mask_dev;
     op->in_h = h; op->in_w = w;
-    *out = op;
-    return DPSX_OK;
+    return finish_create(op, out);
 }
 
 int dpsx_op_create_identity(dpsx_op **out)
@@ -217,8 +231,7 @@ int dpsx_op_create_identity(dpsx_op **out)
     dpsx_op *op = new (std::nothrow) dpsx_op();
     if (!op) return DPSX_ENOMEM;
     op->kind = OP_IDENT;
-    *out = op;
-    return DPSX_OK;
+    return finish_create(op, out);
 }
 
 int dpsx_op_create_phase(int64_t h, int64_t pad, int64_t max_planes, dpsx_op **out)
@@ -230,8 +243,7 @@ int dpsx_op_create_phase(int64_t h, int64_t pad, int64_t max_planes, dpsx_op **o
     op->pr_h = h; op->pr_pad = pad; op->pr_planes = max_planes;
     int rc = phase_create(op);
     if (rc != DPSX_OK) { delete op; return rc; }
-    *out = op;
-    return DPSX_OK;
+    return finish_create(op, out);
 }
 
 void dpsx_op_destroy(dpsx_op *op)
@@ -242,6 +254,7 @@ void dpsx_op_destroy(dpsx_op *op)
     if (op->d_tap_w) (void)hipFree(op->d_tap_w);
     if (op->d_runs_fwd) (void)hipFree(op->d_runs_fwd);
     if (op->d_runs_adj) (void)hipFree(op->d_runs_adj);
+    if (op->d_counters) (void)hipFree(op->d_counters);
     if (op->kind == OP_RESIZE) resize_destroy(op);
     if (op->kind == OP_PHASE) phase_destroy(op);
     delete op;
@@ -470,6 +483,18 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
     StepFwdArgs a{x_t, model_out, noise, y, y_n, x0_hat, sample, inside, static_cast<float *>(resid),
                   ws.partials, n, c, h, w, k};
     int parts = (int)parts_per_particle(op, c, h, w);
+    // norm != NULL: the launch itself finishes the per-particle reduction (each particle's last block re-sums its
+    // partials in the order of k_finalize_norm -- bit-identical, no extra launch)
+    bool tail_done = false;
+    if (norm && op->d_counters && n <= kTailMaxParticles && op->kind != OP_PHASE) {
+        a.tail.counters = op->d_counters;
+        a.tail.partials = ws.partials;
+        a.tail.parts = op->kind == OP_IDENT ? 64 : parts;
+        a.tail.mode = TAIL_L2;
+        a.tail.out = norm;
+        a.tail.n = (int)n;
+        tail_done = true;
+    }
     switch (op->kind) {
     case OP_SEP:
     case OP_TAPS: rc = blur_step_fwd(op, a, s); break;
@@ -485,7 +510,7 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
         rc = posterior_fwd(x_t, model_out, noise, x0_hat, sample, inside, n, chw, k, s);
         if (rc != DPSX_OK) return rc;
         parts = 64;
-        rc = residual_partials(y, y_n, x0_hat, static_cast<float *>(resid), ws.partials, n, chw, parts, s);
+        rc = residual_partials(y, y_n, x0_hat, static_cast<float *>(resid), ws.partials, n, chw, parts, s, 0, a.tail);
         break;
     case OP_PHASE:
         rc = phase_step_fwd(op, a, static_cast<float *>(resid), s);      // S1 + staging + R2C + residual / cotangent
@@ -494,7 +519,7 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
     }
     if (rc != DPSX_OK) return rc;
     // norm == NULL: the partial sums stay in `workspace` and dpsx_step_bwd_f32 finalises them in its prologue
-    return norm ? finalize_norm(ws.partials, parts, norm, n, s) : DPSX_OK;
+    return (norm && !tail_done) ? finalize_norm(ws.partials, parts, norm, n, s) : DPSX_OK;
 }
 
 int dpsx_step_bwd_f32(dpsx_op *op, const void *resid, const float *norm, float *norm_out, const uint8_t *inside,
@@ -572,25 +597,46 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 }
 
 // ------------------------------------------------------------------ best-of-N
-int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,
-                   int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
+// One launch (two for the operators that materialise A x first): residual partials per block, then the launch's own
+// tail finishes costs[p] -- and, when asked, the combine with the previous costs and the argmin over all particles.
+static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, int l1, const float *prev,
+                      int potential, float *raw_out, float *costs, int64_t *best_idx, float *best_val, int64_t n,
+                      int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
 {
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
     if (!x || !y || !costs || (y_n != 1 && y_n != n)) return DPSX_EINVAL;
-    if (n == 0) return DPSX_OK;
+    if (n == 0) return best_idx ? DPSX_EINVAL : DPSX_OK;
     Ws ws;
     if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     int parts = (int)parts_per_particle(op, c, h, w);
+    if (op->kind == OP_IDENT || op->kind == OP_MASK || op->kind == OP_PHASE) parts = 64;
     const int64_t chw = c * h * w;
+    Tail tail{};
+    const bool fused_tail = op->d_counters && n <= kTailMaxParticles;
+    if (fused_tail) {
+        tail.counters = op->d_counters;
+        tail.partials = ws.partials;
+        tail.parts = parts;
+        tail.mode = l1 ? TAIL_L1SQ : TAIL_L2;
+        tail.l1_scale = (float)(1.0 / (double)chw);
+        tail.prev = prev;
+        tail.potential = potential;
+        tail.raw_out = raw_out;
+        tail.out = costs;
+        tail.best_idx = best_idx;
+        tail.best_val = best_val;
+        tail.n = (int)n;
+    } else if (l1 || prev || raw_out) {
+        return DPSX_EUNSUPPORTED;          // > 65536 particles per call: split the batch
+    }
     switch (op->kind) {
     case OP_SEP:
-    case OP_TAPS: rc = blur_score(op, x, y, y_n, ws.partials, n, c, h, w, s); break;
-    case OP_RESIZE: rc = resize_score(op, x, y, y_n, ws.partials, n, c, s); break;
+    case OP_TAPS: rc = blur_score(op, x, y, y_n, ws.partials, n, c, h, w, l1, tail, s); break;
+    case OP_RESIZE: rc = resize_score(op, x, y, y_n, ws.partials, n, c, l1, tail, s); break;
     case OP_IDENT:
-        parts = 64;
-        rc = residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s);
+        rc = residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s, l1, tail);
         break;
     case OP_MASK:
     case OP_PHASE: {
@@ -600,14 +646,39 @@ int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, flo
         if (op->kind == OP_MASK) rc = mask_mul(x, op->mask, ax, n * c, h * w, s);
         else rc = phase_forward(op, x, ax, nullptr, n * c, ws.priv, ws.priv_bytes, s);
         if (rc != DPSX_OK) return rc;
-        parts = 64;
-        rc = residual_partials(y, y_n, ax, nullptr, ws.partials, n, m, parts, s);
+        rc = residual_partials(y, y_n, ax, nullptr, ws.partials, n, m, parts, s, l1, tail);
         break;
     }
     default: return DPSX_EUNSUPPORTED;
     }
-    if (rc != DPSX_OK) return rc;
-    return finalize_norm(ws.partials, parts, costs, n, s);
+    if (rc != DPSX_OK || fused_tail) return rc;
+    if ((rc = finalize_norm(ws.partials, parts, costs, n, s)) != DPSX_OK) return rc;
+    return best_idx ? argmin_f32(costs, n, best_idx, best_val, s) : DPSX_OK;
+}
+
+int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,
+                   int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return score_impl(op, x, y, y_n, 0, nullptr, POT_NONE, nullptr, costs, nullptr, nullptr, n, c, h, w, workspace,
+                      workspace_bytes, stream);
+}
+
+int dpsx_score_argmin_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs,
+                          int64_t *best_idx_dev, float *best_val_dev, int64_t n, int64_t c, int64_t h, int64_t w,
+                          void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!best_idx_dev) return DPSX_EINVAL;
+    return score_impl(op, x, y, y_n, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, c, h, w,
+                      workspace, workspace_bytes, stream);
+}
+
+int dpsx_resample_cost_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, const float *prev_costs,
+                           int potential, float *curr_costs, float *net_costs, int64_t n, int64_t c, int64_t h,
+                           int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (potential < DPSX_POT_MEAN || potential > DPSX_POT_CURR) return DPSX_EINVAL;
+    return score_impl(op, x, y, y_n, 1, prev_costs, potential, curr_costs, net_costs, nullptr, nullptr, n, c, h, w,
+                      workspace, workspace_bytes, stream);
 }
 
 int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, float *val_out_dev, void *stream)

@@ -56,6 +56,9 @@ struct BlurArgs {
     // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
     // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
     int src_h, src_w, src_off;
+    // scoring variants of the residual epilogue (plain input only): sums of |r| instead of r^2; in-launch finalisation
+    int l1;
+    Tail tail;
 };
 
 __device__ __forceinline__ bool block_to_tile(const BlurArgs &a, int &plane, int &ty, int &tx)
@@ -194,13 +197,13 @@ __device__ __forceinline__ float resid_epilogue(const BlurArgs &a, int plane, in
         float4 r;
         r.x = yv.x - acc4[0]; r.y = yv.y - acc4[1]; r.z = yv.z - acc4[2]; r.w = yv.w - acc4[3];
         if (rp) *reinterpret_cast<float4 *>(rp + ox) = r;
-        ss = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+        ss = a.l1 ? fabsf(r.x) + fabsf(r.y) + fabsf(r.z) + fabsf(r.w) : r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
     } else {
         for (int e = 0; e < count; ++e)
             if (ox + e < a.w) {
                 const float r = yp[ox + e] - acc4[e];
                 if (rp) rp[ox + e] = r;
-                ss += r * r;
+                ss += a.l1 ? fabsf(r) : r * r;
             }
     }
     return ss;
@@ -400,7 +403,8 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
         for (int i = 0; i < GI; ++i) {
             const float r = yv[i] - acc[i];
             if (rp) rp[(unsigned)(i * a.w)] = r;
-            ss += r * r;
+            if constexpr (POST) ss += r * r;
+            else ss += a.l1 ? fabsf(r) : r * r;
         }
     } else if (ox < a.w) {
 #pragma unroll
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+        tail_arrive(a.tail, plane / a.c);
     }
 }
 
@@ -781,6 +786,8 @@ int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
     a.y = f.y; a.y_n = (int)f.y_n; a.out = f.resid; a.partials = f.partials;
     a.k = f.k;
     fill_geometry(a, f.n * f.c, f.c, f.h, f.w);
+    a.tail = f.tail;
+    a.tail.blocks_per_particle = a.c * a.tiles_x * a.tiles_y;
     const bool vec = vec_ok(f.h, f.w, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.y, f.resid}) &&
                      (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
     return op->kind == OP_SEP && vec ? dispatch_sep_fwd<true, true>(op, a, s) : launch_taps_fwd<true, true>(op, a, vec, s);
@@ -802,13 +809,16 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &b, float *scratch, int64
 }
 
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,
-               int64_t c, int64_t h, int64_t w, hipStream_t s)
+               int64_t c, int64_t h, int64_t w, int l1, const Tail &tail, hipStream_t s)
 {
     if (!geometry_ok(op, h, w)) return DPSX_EINVAL;
     if (n == 0) return DPSX_OK;
     BlurArgs a{};
     a.x = x; a.y = y; a.y_n = (int)y_n; a.out = nullptr; a.partials = partials;
     fill_geometry(a, n * c, c, h, w);
+    a.l1 = l1;
+    a.tail = tail;
+    a.tail.blocks_per_particle = a.c * a.tiles_x * a.tiles_y;
     const bool vec = vec_ok(h, w, {x, y});
     return op->kind == OP_SEP && vec ? dispatch_sep_fwd<false, true>(op, a, s) : launch_taps_fwd<false, true>(op, a, vec, s);
 }

@@ -567,7 +567,9 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
                 float4 r;
                 r.x = yv[i].x - acc[i][0]; r.y = yv[i].y - acc[i][1]; r.z = yv[i].z - acc[i][2]; r.w = yv[i].w - acc[i][3];
                 if (rp) *reinterpret_cast<float4 *>(rp + (unsigned)(i * a.w)) = r;
-                ss += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;   // same order as resid_epilogue
+                if constexpr (POST) ss += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;   // same order as resid_epilogue
+                else ss += a.l1 ? fabsf(r.x) + fabsf(r.y) + fabsf(r.z) + fabsf(r.w)
+                                : r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
             }
         }
     } else if (ox < a.w && !ABL(8)) {
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+        tail_arrive(a.tail, plane / a.c);
     }
 }
 

@@ -143,6 +143,139 @@ __device__ __forceinline__ void particle_norm_reduce(const NormPartials &p, int 
     }
 }
 
+// -------------------------------------------------------------------- select (torch.argmin order)
+// (value, index) pairs under a total order -- NaN before everything, then the smaller value, then the smaller
+// index -- so the result does not depend on the reduction shape.
+struct ArgMin {
+    float v;
+    int64_t i;   // -1: empty
+};
+
+__device__ __forceinline__ bool argmin_better(const ArgMin &a, const ArgMin &b)   // a strictly before b
+{
+    if (a.i < 0) return false;
+    if (b.i < 0) return true;
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an != bn) return an;
+    if (an) return a.i < b.i;
+    return a.v < b.v || (a.v == b.v && a.i < b.i);
+}
+
+// -------------------------------------------------------------------- "last block done" tail
+// A launch whose blocks each leave one partial sum per (particle, slot) can finish the per-particle reduction
+// itself: every partial-writing block arrives at its particle's counter; the last one re-sums ALL of that particle's
+// partials in the fixed order of k_finalize_norm (so the value is bit-identical to the stand-alone finalisation and
+// independent of which block came last) and writes the per-particle value; optionally the last particle to finish
+// runs the argmin over all values.  Nothing waits on anything: a block that is not last just leaves.  Counters are
+// zero between launches (the last arriver resets its counter).  One launch at a time per counter array (= per
+// dpsx_op): an operator handle is not re-entrant across streams, as its workspace is not either.
+enum { TAIL_L2 = 0,      // value = sqrt(sum of squares)                      ||y - A x||_2
+       TAIL_L1SQ = 1 };  // value = (sum of |.|)^2 * l1_scale                 ||y - A x||_1^2 / (C H W)
+enum { POT_NONE = 0, POT_MEAN = 1, POT_MIN = 2, POT_DIFF = 3, POT_CURR = 4 };   // SearchDDPM.resample_update :565-585
+
+struct Tail {
+    unsigned *counters = nullptr;   // [1 + n]: [0] particles finished, [1 + p] blocks of particle p arrived; null: no tail
+    int blocks_per_particle = 0;
+    const float *partials = nullptr;
+    int parts = 0;
+    int mode = TAIL_L2;
+    float l1_scale = 0.0f;
+    const float *prev = nullptr;    // [n] previous costs (nullable) and how to combine them with the new value
+    int potential = POT_NONE;
+    float *raw_out = nullptr;       // [n] the uncombined value (nullable)
+    float *out = nullptr;           // [n]
+    int64_t *best_idx = nullptr;    // argmin over out[0..n) (nullable)
+    float *best_val = nullptr;      // out[argmin] (nullable)
+    int n = 0;
+};
+
+constexpr int kTailMaxParticles = 1 << 16;    // counters allocated per operator handle
+
+__device__ __forceinline__ float tail_ld(const float *p)      // bypasses the non-coherent caches (other XCDs wrote it)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL threads of every block that wrote a partial of `particle`, after the write (block-uniform call site).
+__device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
+{
+    if (!t.counters) return;                                    // launch-uniform
+    __shared__ int s_tail[49];                                  // flag + 16 x (value, index lo, index hi)
+    int *s_flag = s_tail;
+    __threadfence();                                            // release: this block's partial is visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(&t.counters[1 + particle], 1u);
+        const int last = prev == (unsigned)t.blocks_per_particle - 1u;
+        if (last) t.counters[1 + particle] = 0u;
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;                                       // block-uniform
+    __threadfence();                                            // acquire
+    if (threadIdx.x < kWave) {
+        double acc = 0.0;
+        const float *pp = t.partials + (int64_t)particle * t.parts;
+        for (int i = threadIdx.x; i < t.parts; i += kWave) acc += (double)tail_ld(pp + i);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+        if (threadIdx.x == 0) {
+            float v = t.mode == TAIL_L1SQ ? (float)(acc * acc * (double)t.l1_scale) : (float)sqrt(acc);
+            if (t.raw_out) t.raw_out[particle] = v;
+            if (t.prev) {
+                const float q = t.prev[particle];
+                if (t.potential == POT_MEAN) v = v + q;
+                else if (t.potential == POT_MIN) v = (v != v || q != q) ? __builtin_nanf("") : fminf(v, q);   // torch.min propagates NaN
+                else if (t.potential == POT_DIFF) v = v - q;
+            }
+            __hip_atomic_store(t.out + particle, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!t.best_idx) return;                                    // launch-uniform
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(&t.counters[0], 1u);
+        const int last = prev == (unsigned)t.n - 1u;
+        if (last) t.counters[0] = 0u;
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    __threadfence();
+    // argmin over out[0..n): per-lane scan, wave shuffles, then thread 0 over the waves' winners (one LDS hop)
+    ArgMin best{0.0f, -1};
+    for (int64_t i = threadIdx.x; i < t.n; i += blockDim.x) {
+        const ArgMin c{tail_ld(t.out + i), i};
+        if (argmin_better(c, best)) best = c;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        ArgMin c;
+        c.v = __shfl_down(best.v, o, kWave);
+        c.i = __shfl_down(best.i, o, kWave);
+        if (argmin_better(c, best)) best = c;
+    }
+    float *s_v = reinterpret_cast<float *>(s_flag + 1);
+    int *s_lo = s_flag + 17, *s_hi = s_flag + 33;
+    const int wave = threadIdx.x / kWave, nw = (blockDim.x + kWave - 1) / kWave;
+    __syncthreads();
+    if (threadIdx.x % kWave == 0) {
+        s_v[wave] = best.v;
+        s_lo[wave] = (int)(best.i & 0xffffffff);
+        s_hi[wave] = (int)(best.i >> 32);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) {
+            const ArgMin c{s_v[w], ((int64_t)s_hi[w] << 32) | (uint32_t)s_lo[w]};
+            if (argmin_better(c, best)) best = c;
+        }
+        *t.best_idx = best.i < 0 ? 0 : best.i;
+        if (t.best_val) *t.best_val = best.v;
+    }
+}
+
 // ReflectionPad2d index map (no edge repeat); valid while |overhang| < n.
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
@@ -191,6 +324,8 @@ struct dpsx_op {
     float *d_w_h = nullptr;  // resize.hip keeps its table owner (ResizeHost*) here
     // ---- mask
     const float *mask = nullptr;
+    // ---- "last block done" arrival counters (see Tail): [1 + kTailMaxParticles], zero between launches
+    unsigned *d_counters = nullptr;
     // ---- phase
     int64_t pr_h = 0, pr_pad = 0, pr_planes = 0;
     void *fft_plan = nullptr;  // hipfftHandle stored as integer
@@ -209,6 +344,7 @@ struct StepFwdArgs {
     float *partials;  // [n * parts_per_particle] sums of squares, finalized into norm by the caller
     int64_t n, c, h, w;
     Coefs k;
+    Tail tail{};      // per-particle finalisation inside the launch (tail.counters == nullptr: not requested / not supported)
 };
 
 struct StepBwdArgs {
@@ -234,8 +370,9 @@ int blur_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, in
 int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h, int64_t w);
 int blur_step_fwd(const dpsx_op *op, const StepFwdArgs &a, hipStream_t s);
 int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &a, float *scratch, int64_t scratch_bytes, hipStream_t s);
+// l1: partials are sums of |r| instead of r^2;  tail: finish the reduction inside the launch (see Tail)
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
-               int64_t n, int64_t c, int64_t h, int64_t w, hipStream_t s);
+               int64_t n, int64_t c, int64_t h, int64_t w, int l1, const Tail &tail, hipStream_t s);
 int64_t blur_parts_per_particle(const dpsx_op *op, int64_t c, int64_t h, int64_t w);
 
 // resize.hip
@@ -247,7 +384,7 @@ int resize_adjoint(const dpsx_op *op, const float *u, float *g, int64_t planes, 
 int resize_step_fwd(const dpsx_op *op, const StepFwdArgs &a, hipStream_t s);
 int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
 int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
-                 int64_t n, int64_t c, hipStream_t s);
+                 int64_t n, int64_t c, int l1, const Tail &tail, hipStream_t s);
 
 // elementwise.hip
 int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, float *sample, uint8_t *inside,
@@ -257,7 +394,7 @@ int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const flo
 int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_t hw, hipStream_t s);
 // sums of squares of (y - ax) per particle in `parts` chunks -> partials[n*parts]; r optional
 int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials,
-                      int64_t n, int64_t m, int parts, hipStream_t s);
+                      int64_t n, int64_t m, int parts, hipStream_t s, int l1 = 0, const Tail &tail = Tail{});
 int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipStream_t s);
 int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, float *g_ax,
              int64_t n, int64_t m, hipStream_t s);

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__r
                                                                 const float *__restrict__ ax,
                                                                 float *__restrict__ r,
                                                                 float *__restrict__ partials, int64_t m,
-                                                                int64_t chunk)
+                                                                int64_t chunk, int l1, Tail tail)
 {
     __shared__ float scratch[kThreads / kWave];
     const int64_t p = blockIdx.y, q = blockIdx.x;
@@ -181,18 +181,21 @@ __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__r
     for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
         const float d = __fsub_rn(yp[i], ap[i]);
         if (r) r[p * m + i] = d;
-        acc = fmaf(d, d, acc);
+        acc = l1 ? acc + fabsf(d) : fmaf(d, d, acc);
     }
     const float t = block_sum(acc, scratch);
     if (threadIdx.x == 0) partials[p * gridDim.x + q] = t;
+    tail_arrive(tail, (int)p);
 }
 
 int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials, int64_t n,
-                      int64_t m, int parts, hipStream_t s)
+                      int64_t m, int parts, hipStream_t s, int l1, const Tail &tail)
 {
     if (n == 0) return DPSX_OK;
     const int64_t chunk = (m + parts - 1) / parts;
-    k_residual_partials<<<dim3(parts, (unsigned)n), kThreads, 0, s>>>(y, y_n, ax, r, partials, m, chunk);
+    Tail t = tail;
+    t.blocks_per_particle = parts;
+    k_residual_partials<<<dim3(parts, (unsigned)n), kThreads, 0, s>>>(y, y_n, ax, r, partials, m, chunk, l1, t);
     return check_launch();
 }
 
@@ -363,11 +366,14 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const
     }
     const float t = block_sum(acc, scratch);
     if (threadIdx.x == 0) a.partials[p * gridDim.x + blockIdx.x] = t;
+    tail_arrive(a.tail, (int)p);
 }
 
-int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &a, int parts, hipStream_t s)
+int mask_step_fwd(const dpsx_op *op, const StepFwdArgs &f, int parts, hipStream_t s)
 {
-    const int64_t chw = a.c * a.h * a.w;
+    const int64_t chw = f.c * f.h * f.w;
+    StepFwdArgs a = f;
+    a.tail.blocks_per_particle = parts;
     k_mask_step_fwd<<<dim3(parts, (unsigned)a.n), kThreads, 0, s>>>(a, op->mask, chw, a.h * a.w);
     return check_launch();
 }
@@ -412,21 +418,7 @@ int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s)
 // torch.argmin: first minimum; NaN is the minimum.  One block; n is small (<= a few thousand).
 // (value, index) pairs are reduced with a total order -- NaN before everything, then the smaller value, then the
 // smaller index -- by wave shuffles and one LDS hop, so the result does not depend on the reduction shape.
-struct ArgMin {
-    float v;
-    int64_t i;   // -1: empty
-};
-
-__device__ __forceinline__ bool argmin_better(const ArgMin &a, const ArgMin &b)   // a strictly before b
-{
-    if (a.i < 0) return false;
-    if (b.i < 0) return true;
-    const bool an = a.v != a.v, bn = b.v != b.v;
-    if (an != bn) return an;
-    if (an) return a.i < b.i;
-    return a.v < b.v || (a.v == b.v && a.i < b.i);
-}
-
+// (ArgMin / argmin_better: common.h, shared with the in-launch tail)
 __global__ __launch_bounds__(kThreads) void k_argmin(const float *__restrict__ v, int64_t n, int64_t *__restrict__ out,
                                                      float *__restrict__ val_out)
 {

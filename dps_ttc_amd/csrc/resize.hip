@@ -64,6 +64,8 @@ struct ResizeArgs {
     int power;
     int c, planes;
     Coefs k;
+    int l1;                   // scoring (plain input): partials are sums of |r|
+    Tail tail;                // in-launch finalisation of the per-particle reduction (common.h)
 };
 
 __device__ __forceinline__ float norm_coef_r(float nv, float gn, int power)
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
             const float r = yv - acc;
             if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
-            ss = fmaf(r, r, ss);
+            if constexpr (POST) ss = fmaf(r, r, ss);
+            else ss = a.l1 ? ss + fabsf(r) : fmaf(r, r, ss);
         } else {
             a.out[(int64_t)plane * ohw + oo] = acc;
         }
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+        tail_arrive(a.tail, plane / a.c);
     }
 }
 
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
             const float r = yv - acc;
             if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
-            ss = fmaf(r, r, ss);
+            if constexpr (POST) ss = fmaf(r, r, ss);
+            else ss = a.l1 ? ss + fabsf(r) : fmaf(r, r, ss);
         } else {
             a.out[(int64_t)plane * ohw + oo] = acc;
         }
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+        tail_arrive(a.tail, plane / a.c);
     }
 }
 
@@ -736,6 +742,8 @@ int resize_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
     a.x_t = f.x_t; a.model_out = f.model_out; a.noise = f.noise; a.x0_hat = f.x0_hat; a.sample = f.sample;
     a.inside_w = f.inside; a.y = f.y; a.y_n = (int)f.y_n; a.out = f.resid; a.partials = f.partials;
     a.c = (int)f.c; a.planes = (int)(f.n * f.c); a.k = f.k;
+    a.tail = f.tail;
+    a.tail.blocks_per_particle = (int)resize_parts_per_particle(op, f.c);
     const bool vec = rz_vec(op, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample}) &&
                      (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
     return launch_fwd<true, true>(op, a, vec, s);
@@ -753,12 +761,15 @@ int resize_step_bwd(const dpsx_op *op, const StepBwdArgs &b, hipStream_t s)
 }
 
 int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials, int64_t n,
-                 int64_t c, hipStream_t s)
+                 int64_t c, int l1, const Tail &tail, hipStream_t s)
 {
     if (n == 0) return DPSX_OK;
     ResizeArgs a{};
     a.x = x; a.y = y; a.y_n = (int)y_n; a.out = nullptr; a.partials = partials; a.c = (int)c;
     a.planes = (int)(n * c);
+    a.l1 = l1;
+    a.tail = tail;
+    a.tail.blocks_per_particle = (int)resize_parts_per_particle(op, c);
     return launch_fwd<false, true>(op, a, rz_vec(op, {x}), s);
 }
 

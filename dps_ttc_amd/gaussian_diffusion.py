@@ -458,10 +458,11 @@ class SearchDDPM(DDPM):
         if noise is None:
             noise = self._randn(img)
         _, sample = kernels.posterior_fwd(img, model_out, noise, self.step_coefs[idx], want_x0=False)
-        costs = handle.score(sample, measurement)
         if self.global_select is not None:
+            costs = handle.score(sample, measurement)
             return self.global_select(costs, sample), costs
-        best = kernels.argmin(costs)
+        costs, best, _ = handle.score_argmin(sample, measurement)      # norms + select finished by the scoring launch
+        self.last_best = best
         return kernels.replicate(sample, best), costs
 
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, operator,
@@ -481,31 +482,29 @@ class SearchDDPM(DDPM):
 
     @torch.no_grad()
     def resample_update(self, candidates, denoised_candidates, operator, measurement, resample=True, rs_temp=0.01,
-                        prev_costs=None, potential_type='min', steps_done=1):
-        """reference :515-587 (defined there, never called): multinomial resampling on accumulated costs.
-        The draw is torch.multinomial for RNG parity; the particle gather is HIP."""
+                        prev_costs=None, potential_type='min', steps_done=1, **kwargs):
+        """reference :515-587 (defined there, never called by its loops): multinomial resampling on the accumulated
+        costs, then the cost update.  The draw is torch.multinomial ([N] weights, RNG parity); the particle gathers
+        and the cost update -- ||y - A(x)||_1^2 / CHW per particle combined with the previous costs by
+        `potential_type` -- are HIP (dpsx_gather_f32, dpsx_resample_cost_f32: one launch).
+        kwargs: `mask` for inpainting (the reference calls operator.forward without it and raises there)."""
+        if potential_type not in ('mean', 'min', 'diff', 'curr'):
+            raise NotImplementedError
         n = denoised_candidates.shape[0]
         if resample and prev_costs is not None:
             pot = torch.exp(-rs_temp * prev_costs / steps_done) if potential_type == 'mean' \
                 else torch.exp(-rs_temp * prev_costs)
-            if pot.max() != pot.min():
-                ids = torch.multinomial(pot, n, replacement=True)
+            if pot.max() != pot.min():                                                     # :545
+                ids = torch.multinomial(pot.cpu(), n, replacement=True).to(pot.device) if self.rng_parity \
+                    else torch.multinomial(pot, n, replacement=True)
+                self.last_resample_ids = ids
                 candidates = kernels.gather(candidates, ids)
                 denoised_candidates = kernels.gather(denoised_candidates, ids)
-                prev_costs = prev_costs[ids]
-        Ax = operator.forward(denoised_candidates)
-        delta = (measurement - Ax).reshape(n, -1)
-        curr = torch.linalg.norm(delta, dim=-1, ord=1) ** 2 / denoised_candidates[0].numel()
-        if potential_type == 'mean':
-            net = curr if prev_costs is None else curr + prev_costs
-        elif potential_type == 'min':
-            net = curr if prev_costs is None else torch.minimum(curr, prev_costs)
-        elif potential_type == 'diff':
-            net = curr if prev_costs is None else curr - prev_costs
-        elif potential_type == 'curr':
-            net = curr
-        else:
-            raise NotImplementedError
+                prev_costs = kernels.gather(prev_costs.reshape(n, 1), ids).reshape(n)
+        mask = kwargs.get('mask', None)
+        handle = operator.hip_handle_for(mask) if operator.name == 'inpainting' \
+            else operator.hip_handle(denoised_candidates)
+        self.last_curr_costs, net = handle.resample_cost(denoised_candidates, measurement, prev_costs, potential_type)
         return candidates, net
 
 

@@ -189,6 +189,39 @@ class OpHandle:
                                    ws.numel(), stream_of(x)), "dpsx_score_f32")
         return costs
 
+    def score_argmin(self, x, y):
+        """-> (costs [N], best int64 scalar, costs[best] [1]) -- the scoring launch finishes the per-particle norms
+        and the torch.argmin-order select itself (gaussian_diffusion.py:626-632); everything stays on the device."""
+        x, y = _nchw(f32c(x)), f32c(y)
+        n, c, h, w = x.shape
+        if n == 0:
+            raise ValueError("best-of-N over an empty particle set")
+        costs = torch.empty(n, dtype=torch.float32, device=x.device)
+        best = torch.empty((), dtype=torch.int64, device=x.device)
+        val = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = self.workspace(n, c, h, w, x.device)
+        check(lib().dpsx_score_argmin_f32(self._h, ptr(x), ptr(y), y.shape[0], ptr(costs), ptr(best), ptr(val),
+                                          n, c, h, w, ptr(ws), ws.numel(), stream_of(x)), "dpsx_score_argmin_f32")
+        return costs, best, val
+
+    def resample_cost(self, x, y, prev_costs=None, potential_type='min'):
+        """SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585) in one launch:
+        curr[p] = ||y - A(x_p)||_1^2 / (C H W), net = combine(curr, prev_costs) -> (curr, net)."""
+        if potential_type not in _lib.POTENTIALS:
+            raise NotImplementedError(potential_type)
+        x, y = _nchw(f32c(x)), f32c(y)
+        n, c, h, w = x.shape
+        prev = None if prev_costs is None else f32c(prev_costs.reshape(-1), "prev_costs")
+        if prev is not None and prev.numel() != n:
+            raise ValueError("prev_costs must hold one cost per particle")
+        curr = torch.empty(n, dtype=torch.float32, device=x.device)
+        net = torch.empty(n, dtype=torch.float32, device=x.device)
+        ws = self.workspace(n, c, h, w, x.device)
+        check(lib().dpsx_resample_cost_f32(self._h, ptr(x), ptr(y), y.shape[0], ptr(prev),
+                                           _lib.POTENTIALS[potential_type], ptr(curr), ptr(net), n, c, h, w,
+                                           ptr(ws), ws.numel(), stream_of(x)), "dpsx_resample_cost_f32")
+        return curr, net
+
 
 def _cuda_device(device):
     dev = torch.device(device)
@@ -331,9 +364,11 @@ class StepBuffers:
         self.flip = 0
 
 
-def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False):
-    """K1.  With finalize_norm=False (the loop's setting) buf.norm is filled by the following step_bwd, whose
-    prologue finalises the per-tile partial sums this launch leaves in the workspace (one launch fewer)."""
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=True):
+    """K1.  finalize_norm=True (the loop's setting): the launch finishes buf.norm itself -- each particle's last
+    block re-sums the per-tile partial sums in a fixed order -- and step_bwd reads one float per particle.
+    finalize_norm=False: buf.norm is filled by the following step_bwd, whose prologue finalises the partial sums
+    this launch leaves in the workspace.  Same bits either way."""
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, x_t.device)
     buf.norm_ready = bool(finalize_norm)

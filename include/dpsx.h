@@ -144,7 +144,9 @@ int dpsx_norm_bwd_f32(const float *r, const float *norm, const float *g_norm, in
  * the residual (or, for phase retrieval, the complex cotangent) from fwd to bwd. */
 int64_t dpsx_step_resid_bytes(const dpsx_op *op, int64_t n, int64_t c, int64_t h, int64_t w);
 
-/* norm may be NULL: the per-particle norms are then finalised by dpsx_step_bwd_f32 (see there). */
+/* norm != NULL: the launch finishes the per-particle norms itself (each particle's last block re-sums the partials
+ * in a fixed order: deterministic, no extra launch).  norm == NULL: they are finalised by dpsx_step_bwd_f32's
+ * prologue from the partial sums left in `workspace` (see there). */
 int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise,
                       const float *y, int64_t y_n,
                       float *x0_hat, float *sample, uint8_t *inside, void *resid, float *norm,
@@ -185,6 +187,24 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs,
                    int64_t n, int64_t c, int64_t h, int64_t w,
                    void *workspace, int64_t workspace_bytes, void *stream);
+/* The same scoring with the select fused in (gaussian_diffusion.py:626-631): costs[p] as above, *best_idx_dev =
+ * argmin_p costs[p] (torch.argmin: first minimum, NaN counts as the minimum) and, if best_val_dev != NULL, its cost
+ * -- finished by the scoring launch itself ("last block done"), no separate reduction / argmin launches. */
+int dpsx_score_argmin_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs,
+                          int64_t *best_idx_dev, float *best_val_dev,
+                          int64_t n, int64_t c, int64_t h, int64_t w,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+
+/* SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585):
+ *   curr[p] = ||y - A(x_p)||_1^2 / (c*h*w)                                         (:557-563)
+ *   net[p]  = curr + prev (MEAN) | min(curr, prev) (MIN, NaN propagates as torch.min) | curr - prev (DIFF) | curr (CURR)
+ * prev_costs == NULL (first call, :566-579) gives net = curr for every potential.  curr_costs may be NULL. */
+enum { DPSX_POT_MEAN = 1, DPSX_POT_MIN = 2, DPSX_POT_DIFF = 3, DPSX_POT_CURR = 4 };
+int dpsx_resample_cost_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, const float *prev_costs,
+                           int potential, float *curr_costs, float *net_costs,
+                           int64_t n, int64_t c, int64_t h, int64_t w,
+                           void *workspace, int64_t workspace_bytes, void *stream);
+
 /* torch.argmin semantics: first minimum wins, NaN counts as the minimum (gaussian_diffusion.py:631).
  * val_out_dev (optional, may be NULL) receives v[argmin] -- `costs[best_path]` of :632 without a host index. */
 int dpsx_argmin_f32(const float *v, int64_t n, int64_t *idx_out_dev, float *val_out_dev, void *stream);

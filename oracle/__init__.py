@@ -226,6 +226,38 @@ def gather(src, ids):
     return dst
 
 
+def resample_cost(op, x, y, prev_costs=None, potential_type="min"):
+    """Cost update of SearchDDPM.resample_update (gaussian_diffusion.py:556-585):
+    curr[p] = ||y - A(x_p)||_1^2 / (C H W) (:557-563); net by potential type (:565-585).  -> (curr, net) float32."""
+    x = _f(x)
+    n = x.shape[0]
+    ax = op.forward(x)
+    yy = np.broadcast_to(_f(y), ax.shape) if _f(y).shape[0] == 1 else _f(y)
+    l1 = np.abs(yy.astype(np.float64) - ax.astype(np.float64)).reshape(n, -1).sum(axis=1)
+    curr = (l1 ** 2 / float(np.prod(x.shape[1:]))).astype(np.float32)
+    if potential_type not in ("mean", "min", "diff", "curr"):
+        raise NotImplementedError(potential_type)
+    if prev_costs is None or potential_type == "curr":
+        return curr, curr.copy()
+    prev = _f(prev_costs)
+    if potential_type == "mean":
+        net = curr + prev
+    elif potential_type == "min":
+        net = np.where(np.isnan(curr) | np.isnan(prev), np.float32(np.nan), np.minimum(curr, prev))
+    else:
+        net = curr - prev
+    return curr, net.astype(np.float32)
+
+
+def resample_update(op, candidates, denoised, y, prev_costs=None, potential_type="min", ids=None):
+    """SearchDDPM.resample_update (gaussian_diffusion.py:515-587) for a GIVEN multinomial draw `ids` (the draw itself
+    is torch.multinomial on exp(-rs_temp * prev / steps), :539-546; None = no resampling) -> (candidates, net)."""
+    candidates, denoised = _f(candidates), _f(denoised)
+    if ids is not None and prev_costs is not None:
+        candidates, denoised, prev_costs = gather(candidates, ids), gather(denoised, ids), _f(prev_costs)[np.asarray(ids)]
+    return candidates, resample_cost(op, denoised, y, prev_costs, potential_type)[1]
+
+
 # ---------------------------------------------------------------- operator objects
 class Operator:
     """forward / adjoint pair for one measurement operator (linear unless noted)."""

@@ -302,6 +302,7 @@ def main():
     save("search.npz", **out)
     ddim_fixtures(GD, CM, MS)
     project_fixtures(GD, CM, MS)
+    resample_fixtures(GD, CM, MS)
 
 
 def ddim_fixtures(GD, CM, MS):
@@ -413,8 +414,52 @@ def project_fixtures(GD, CM, MS):
     save("project.npz", **out)
 
 
+def resample_fixtures(GD, CM, MS):
+    """9. SearchDDPM.resample_update (gaussian_diffusion.py:515-587), called directly (no loop of the reference calls
+    it): all four potential types x {first call, update without resampling, resample + update} -> resample.npz"""
+    out = {}
+    with quiet():
+        smp = GD.create_sampler(sampler="search_ddpm", timestep_respacing="20", **DIFF)
+    gb = MS.get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device="cpu")
+    sr4 = MS.get_operator("super_resolution", in_shape=(1, 3, 64, 64), scale_factor=4, device="cpu")
+    n = 6
+    for tag, op, seed in (("gauss", gb, 90), ("sr4", sr4, 91)):
+        gen = torch.Generator().manual_seed(seed)
+        truth = torch.rand(1, 3, 64, 64, generator=gen) * 2 - 1
+        y = op.forward(truth)
+        y = y + 0.05 * torch.randn(*y.shape, generator=gen)
+        # denoised candidates at different distances from the truth; candidates carry their index in one pixel
+        spread = torch.tensor([0.02, 0.3, 0.1, 0.6, 0.05, 0.2]).view(n, 1, 1, 1)
+        denoised = (truth + spread * torch.randn(n, 3, 64, 64, generator=gen)).clamp(-1, 1)
+        cands = torch.randn(n, 3, 64, 64, generator=gen)
+        cands[:, 0, 0, 0] = torch.arange(n, dtype=torch.float32)
+        prev = torch.rand(n, generator=gen) * 60.0 + 1.0
+        out[f"{tag}.y"] = np32(y)
+        out[f"{tag}.denoised"] = np32(denoised)
+        out[f"{tag}.candidates"] = np32(cands)
+        out[f"{tag}.prev_costs"] = np32(prev)
+        for pot in ("mean", "min", "diff", "curr"):
+            cases = (("first", dict(prev_costs=None, resample=True)),
+                     ("noresample", dict(prev_costs=prev.clone(), resample=False)),
+                     ("resample", dict(prev_costs=prev.clone(), resample=True, rs_temp=0.05, steps_done=3)))
+            for cname, kw in cases:
+                torch.manual_seed(500 + seed)
+                with quiet():
+                    c2, net = smp.resample_update(cands.clone(), denoised.clone(), op, y, potential_type=pot, **kw)
+                out[f"{tag}.{pot}.{cname}.net"] = np32(net)
+                out[f"{tag}.{pot}.{cname}.ids"] = c2[:, 0, 0, 0].round().numpy().astype(np.int64)
+        out[f"{tag}.rng_seed"] = np.int64(500 + seed)
+    # equal potentials: the draw is skipped (:545)
+    torch.manual_seed(1)
+    with quiet():
+        c2, net = smp.resample_update(cands.clone(), denoised.clone(), gb, torch.from_numpy(out["gauss.y"]),
+                                      prev_costs=torch.full((n,), 7.0), resample=True, potential_type="min")
+    out["gauss.flat.ids"] = c2[:, 0, 0, 0].round().numpy().astype(np.int64)
+    save("resample.npz", **out)
+
+
 if __name__ == "__main__":
-    extra = {"--only-ddim": ddim_fixtures, "--only-project": project_fixtures}
+    extra = {"--only-ddim": ddim_fixtures, "--only-project": project_fixtures, "--only-resample": resample_fixtures}
     chosen = [fn for flag, fn in extra.items() if flag in sys.argv]
     if chosen:                          # add fixtures without rewriting the others
         install_stubs()

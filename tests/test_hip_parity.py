@@ -780,3 +780,115 @@ def test_argmin_gather_replicate(K, oracle, golden):
     torch.manual_seed(int(g["resample.seed"]))
     ids = torch.multinomial(w, 8, replacement=True)
     np.testing.assert_array_equal(ids.numpy(), g["resample.ids"])
+
+
+# ----------------------------------------------------------------- resample_update (reference :515-587) and fused selects
+@pytest.mark.parametrize("tag,oname", [("gauss", "gauss"), ("sr4", "sr4")])
+def test_resample_update_golden(K, golden, tag, oname):
+    """SearchDDPM.resample_update against the reference's own outputs: multinomial ids bit-exact on the replayed host
+    RNG stream, net costs within 1e-5, for every potential type x {first call, update, resample + update};
+    gathers and the L1^2 / CHW cost + combine are HIP (dpsx_gather_f32, dpsx_resample_cost_f32)."""
+    g = golden("resample")
+    op, _ = make_product_op(oname, hw=64)
+    smp = _sampler("search_ddpm", "20")
+    cands, den, y, prev = dev(g[f"{tag}.candidates"]), dev(g[f"{tag}.denoised"]), dev(g[f"{tag}.y"]), dev(g[f"{tag}.prev_costs"])
+    for pot in ("mean", "min", "diff", "curr"):
+        cases = (("first", dict(prev_costs=None, resample=True)),
+                 ("noresample", dict(prev_costs=prev.clone(), resample=False)),
+                 ("resample", dict(prev_costs=prev.clone(), resample=True, rs_temp=0.05, steps_done=3)))
+        for cname, kw in cases:
+            torch.manual_seed(int(g[f"{tag}.rng_seed"]))
+            c2, net = smp.resample_update(cands.clone(), den.clone(), op, y, potential_type=pot, **kw)
+            np.testing.assert_array_equal(host(c2)[:, 0, 0, 0].round().astype(np.int64), g[f"{tag}.{pot}.{cname}.ids"])
+            assert rel_l2(host(net), g[f"{tag}.{pot}.{cname}.net"]) < TOL, (pot, cname)
+    # equal potentials: no draw, particles untouched (:545)
+    c2, _ = smp.resample_update(cands.clone(), den.clone(), op, y, prev_costs=torch.full((6,), 7.0, device=DEV),
+                                resample=True, potential_type="min")
+    assert torch.equal(c2, cands)
+    with pytest.raises(NotImplementedError):
+        smp.resample_update(cands, den, op, y, potential_type="median")
+
+
+@pytest.mark.parametrize("name,hw,n", [("gauss", 256, 5), ("motion", 256, 3), ("sr4", 256, 5), ("sr8", 256, 3),
+                                       ("inpaint", 256, 4), ("phase", 256, 2), ("gauss", 46, 3), ("sr4", 36, 3),
+                                       ("inpaint", 30, 3)])
+def test_resample_cost_vs_oracle(K, oracle, name, hw, n):
+    """curr = ||y - A x||_1^2 / CHW and the four combines for every operator (full size and ragged), against the oracle;
+    NaN in either cost propagates through 'min' as torch.min does"""
+    rng = np.random.RandomState(hw + n)
+    kernel = synthetic_motion_kernel(61, 5)
+    mask = (np.random.RandomState(3).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=kernel, mask=mask)
+    orc = make_oracle_op(oracle, name, hw=hw, kernel=kernel, mask=mask)
+    x = rng.uniform(-1, 1, (n, 3, hw, hw)).astype(np.float32)
+    y = orc.forward(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32))
+    y = (y + 0.05 * rng.randn(*y.shape)).astype(np.float32)
+    handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(dev(x))
+    prev = (rng.rand(n) * 50).astype(np.float32)
+    for pot in ("mean", "min", "diff", "curr"):
+        for pv in (None, prev):
+            curr, net = handle.resample_cost(dev(x), dev(y), None if pv is None else dev(pv), pot)
+            oc, on = oracle.resample_cost(orc, x, y, pv, pot)
+            assert rel_l2(host(curr), oc) < TOL and rel_l2(host(net), on) < TOL, (pot, pv is None)
+    pn = prev.copy()
+    pn[1] = np.nan
+    _, net = handle.resample_cost(dev(x), dev(y), dev(pn), "min")
+    assert np.isnan(host(net)[1]) and not np.isnan(host(net)[0])
+    # per-particle measurements
+    yn = np.repeat(y, n, axis=0) + 0.01 * rng.randn(n, *y.shape[1:]).astype(np.float32)
+    curr, _ = handle.resample_cost(dev(x), dev(yn.astype(np.float32)), None, "curr")
+    assert rel_l2(host(curr), oracle.resample_cost(orc, x, yn.astype(np.float32), None, "curr")[0]) < TOL
+
+
+@pytest.mark.parametrize("name,hw,n", [("gauss", 256, 64), ("motion", 128, 9), ("sr4", 256, 64), ("inpaint", 256, 33),
+                                       ("phase", 256, 3), ("gauss", 46, 7), ("sr4", 64, 300)])
+def test_score_argmin_fused(K, name, hw, n):
+    """dpsx_score_argmin_f32: the scoring launch's own tail finishes the norms and the select -- same costs bit for bit
+    as dpsx_score_f32, same index as torch.argmin (first minimum; NaN wins), repeatable (counters reset themselves)"""
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    mask = (np.random.RandomState(3).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5), mask=mask)
+    x = torch.randn(n, 3, hw, hw, device=DEV, generator=gen)
+    x[n // 2] = x[1]                                         # an exact tie: the first one must win
+    handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(x)
+    y = op.forward(x[1:2] * 0.9, **fkw).detach().contiguous()
+    for rep in range(3):
+        costs, best, val = handle.score_argmin(x, y)
+        ref = handle.score(x, y)
+        assert torch.equal(costs, ref)
+        assert int(best) == int(torch.argmin(ref)) == 1 and float(val) == float(ref[1])
+    xn = x.clone()
+    xn[n - 1, 0, 3, 3] = float("nan")
+    costs, best, val = handle.score_argmin(xn, y)
+    assert int(best) == n - 1 and bool(torch.isnan(val).all())
+
+
+@pytest.mark.parametrize("name,hw", [("gauss", 256), ("motion", 128), ("sr4", 256), ("inpaint", 256), ("gauss", 46)])
+def test_step_fwd_norm_modes_bit_identical(K, name, hw):
+    """K1 finishing the norm itself (last block of each particle) == the stand-alone finalisation kernel of r01 ==
+    K2's prologue finalisation: the same bits, and repeatable over launches (self-resetting counters)"""
+    rng = np.random.RandomState(hw)
+    n = 5
+    mask = (np.random.RandomState(7).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5), mask=mask)
+    x, mo, z = dev(rng.randn(n, 3, hw, hw).astype(np.float32)), dev(rng.randn(n, 6, hw, hw).astype(np.float32) * 0.4), \
+        dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    y = op.forward(dev(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32)), **fkw).detach().contiguous()
+    handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(x)
+    ck = _sampler("ddpm", "").step_coefs[400]
+    outs = []
+    for finalize in (True, False, True, True):
+        buf = K.StepBuffers(handle, n, 3, hw, hw, DEV)
+        buf.norm.fill_(-1.0)
+        K.step_fwd(handle, buf, x, mo, z, y, ck, finalize_norm=finalize)
+        if finalize:
+            first = buf.norm.clone()
+            assert float(first.min()) > 0
+        K.step_bwd(handle, buf, y, 0.5, 1, ck)
+        if finalize:
+            assert torch.equal(first, buf.norm)
+        outs.append((buf.norm.clone(), buf.g_model_out.clone()))
+    for a, b in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])
+    r = (y - op.forward(buf.x0_hat, **fkw)).reshape(n, -1)
+    assert rel_l2(host(outs[0][0]), host(r.norm(dim=1))) < TOL

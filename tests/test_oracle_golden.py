@@ -211,3 +211,21 @@ def test_ddim_step_golden(oracle, golden, t, eta):
     assert rel_l2(gx, g[f"{tag}.g_x"]) < 1e-5
     assert rel_l2(gmo, g[f"{tag}.g_model_out"]) < 1e-5
     assert np.all(gmo[:, 3:] == 0)          # DDIM ignores the variance channels
+
+
+@pytest.mark.parametrize("tag,opname,cfg", [("gauss", "gaussian_blur", dict(kernel_size=61, intensity=3.0)),
+                                            ("sr4", "super_resolution", dict(in_shape=(1, 3, 64, 64), scale_factor=4))])
+def test_resample_update_golden(oracle, golden, tag, opname, cfg):
+    """SearchDDPM.resample_update of the reference (gaussian_diffusion.py:515-587), all potential types, first call /
+    update / resample + update: the oracle's cost update reproduces the reference's net costs for the reference's draw"""
+    g = golden("resample")
+    op = oracle.make_operator(opname, **cfg)
+    for pot in ("mean", "min", "diff", "curr"):
+        for case in ("first", "noresample", "resample"):
+            ids = g[f"{tag}.{pot}.{case}.ids"]
+            prev = None if case == "first" else g[f"{tag}.prev_costs"]
+            cands, net = oracle.resample_update(op, g[f"{tag}.candidates"], g[f"{tag}.denoised"], g[f"{tag}.y"], prev,
+                                                pot, ids=ids if case == "resample" else None)
+            assert rel_l2(net, g[f"{tag}.{pot}.{case}.net"]) < TOL, (pot, case)
+            np.testing.assert_array_equal(cands[:, 0, 0, 0].round().astype(np.int64), ids)
+    assert list(g["gauss.flat.ids"]) == list(range(6))

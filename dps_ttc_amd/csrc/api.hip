@@ -597,8 +597,8 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 }
 
 // ------------------------------------------------------------------ best-of-N
-// One launch (two for the operators that materialise A x first): residual partials per block, then the launch's own
-// tail finishes costs[p] -- and, when asked, the combine with the previous costs and the argmin over all particles.
+// Residual partials per block (one launch; two for the operators that materialise A x first), then one small launch
+// that finishes costs[p] and, when asked, the combine with the previous costs and the argmin over all particles.
 static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, int l1, const float *prev,
                       int potential, float *raw_out, float *costs, int64_t *best_idx, float *best_val, int64_t n,
                       int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
@@ -613,24 +613,21 @@ static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, 
     int parts = (int)parts_per_particle(op, c, h, w);
     if (op->kind == OP_IDENT || op->kind == OP_MASK || op->kind == OP_PHASE) parts = 64;
     const int64_t chw = c * h * w;
-    Tail tail{};
-    const bool fused_tail = op->d_counters && n <= kTailMaxParticles;
-    if (fused_tail) {
-        tail.counters = op->d_counters;
-        tail.partials = ws.partials;
-        tail.parts = parts;
-        tail.mode = l1 ? TAIL_L1SQ : TAIL_L2;
-        tail.l1_scale = (float)(1.0 / (double)chw);
-        tail.prev = prev;
-        tail.potential = potential;
-        tail.raw_out = raw_out;
-        tail.out = costs;
-        tail.best_idx = best_idx;
-        tail.best_val = best_val;
-        tail.n = (int)n;
-    } else if (l1 || prev || raw_out) {
-        return DPSX_EUNSUPPORTED;          // > 65536 particles per call: split the batch
-    }
+    // the reduction is finished by one small follow-up launch (finalize_select), not inside the scoring launch: see
+    // the measurement at k_finalize_select
+    Tail fin{};
+    fin.partials = ws.partials;
+    fin.parts = parts;
+    fin.mode = l1 ? TAIL_L1SQ : TAIL_L2;
+    fin.l1_scale = (float)(1.0 / (double)chw);
+    fin.prev = prev;
+    fin.potential = potential;
+    fin.raw_out = raw_out;
+    fin.out = costs;
+    fin.best_idx = best_idx;
+    fin.best_val = best_val;
+    fin.n = (int)n;
+    const Tail tail{};                     // no in-launch tail
     switch (op->kind) {
     case OP_SEP:
     case OP_TAPS: rc = blur_score(op, x, y, y_n, ws.partials, n, c, h, w, l1, tail, s); break;
@@ -651,9 +648,8 @@ static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, 
     }
     default: return DPSX_EUNSUPPORTED;
     }
-    if (rc != DPSX_OK || fused_tail) return rc;
-    if ((rc = finalize_norm(ws.partials, parts, costs, n, s)) != DPSX_OK) return rc;
-    return best_idx ? argmin_f32(costs, n, best_idx, best_val, s) : DPSX_OK;
+    if (rc != DPSX_OK) return rc;
+    return finalize_select(fin, s);
 }
 
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,

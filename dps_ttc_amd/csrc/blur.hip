@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = t;
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t);
         tail_arrive(a.tail, plane / a.c);
     }
 }
@@ -604,7 +604,7 @@ static int allow_lds(K kernel, size_t bytes, bool &done)
 {
     if (!done) {
         DPSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
         done = true;
     }
     (void)bytes;

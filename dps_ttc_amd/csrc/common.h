@@ -191,9 +191,20 @@ struct Tail {
 
 constexpr int kTailMaxParticles = 1 << 16;    // counters allocated per operator handle
 
-__device__ __forceinline__ float tail_ld(const float *p)      // bypasses the non-coherent caches (other XCDs wrote it)
+// Visibility across the 8 XCDs (one L2 each) WITHOUT a device-scope release fence: on gfx950 that fence is a write-back
+// of the whole L2 (`buffer_wbl2`), and with megabytes of freshly written x0_hat / sample lines dirty in it, one fence per
+// block cost 535 us per launch (measured, N = 64).  Instead the few words that other blocks must see -- the partial sums,
+// the finished values -- are written with agent-scope atomic stores (write-through past the XCD's L2), the writer waits
+// for their completion (s_waitcnt) before it bumps the counter, and only the LAST block of a particle (N blocks per
+// launch) pays an acquire fence (an L2 invalidate of non-local lines, no write-back) before it reads them back with
+// agent-scope atomic loads.
+__device__ __forceinline__ float tail_ld(const float *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tail_publish(float *p, float v)      // a partial sum other blocks will read
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Called by ALL threads of every block that wrote a partial of `particle`, after the write (block-uniform call site).
@@ -202,17 +213,17 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
     if (!t.counters) return;                                    // launch-uniform
     __shared__ int s_tail[49];                                  // flag + 16 x (value, index lo, index hi)
     int *s_flag = s_tail;
-    __threadfence();                                            // release: this block's partial is visible device-wide
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = atomicAdd(&t.counters[1 + particle], 1u);
+    if (threadIdx.x == 0) {                                     // the thread that published the partial
+        __builtin_amdgcn_s_waitcnt(0);                          // ... whose write-through store has completed
+        const unsigned prev = __hip_atomic_fetch_add(&t.counters[1 + particle], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)t.blocks_per_particle - 1u;
-        if (last) t.counters[1 + particle] = 0u;
+        if (last) __hip_atomic_store(&t.counters[1 + particle], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last;
     }
     __syncthreads();
     if (!*s_flag) return;                                       // block-uniform
-    __threadfence();                                            // acquire
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // invalidate, no write-back; N blocks per launch
     if (threadIdx.x < kWave) {
         double acc = 0.0;
         const float *pp = t.partials + (int64_t)particle * t.parts;
@@ -232,17 +243,17 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
         }
     }
     if (!t.best_idx) return;                                    // launch-uniform
-    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = atomicAdd(&t.counters[0], 1u);
+    if (threadIdx.x == 0) {                                     // the thread that stored out[particle]
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned prev = __hip_atomic_fetch_add(&t.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)t.n - 1u;
-        if (last) t.counters[0] = 0u;
+        if (last) __hip_atomic_store(&t.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last;
     }
     __syncthreads();
     if (!*s_flag) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // argmin over out[0..n): per-lane scan, wave shuffles, then thread 0 over the waves' winners (one LDS hop)
     ArgMin best{0.0f, -1};
     for (int64_t i = threadIdx.x; i < t.n; i += blockDim.x) {
@@ -396,6 +407,9 @@ int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_
 int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials,
                       int64_t n, int64_t m, int parts, hipStream_t s, int l1 = 0, const Tail &tail = Tail{});
 int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipStream_t s);
+// one small launch: per-particle values from the partials (t.partials / parts / mode / prev / potential -> raw_out, out)
+// and, if t.best_idx, the torch.argmin-order select over them (t.counters is not used)
+int finalize_select(const Tail &t, hipStream_t s);
 int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, float *g_ax,
              int64_t n, int64_t m, hipStream_t s);
 // g_model_out[:, :c] = -b * (inside ? coef_p * g_x0 : 0),  g_x0 = A^T r

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__r
         acc = l1 ? acc + fabsf(d) : fmaf(d, d, acc);
     }
     const float t = block_sum(acc, scratch);
-    if (threadIdx.x == 0) partials[p * gridDim.x + q] = t;
+    if (threadIdx.x == 0) tail_publish(&partials[p * gridDim.x + q], t);
     tail_arrive(tail, (int)p);
 }
 
@@ -215,6 +215,75 @@ int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipS
 {
     if (n == 0) return DPSX_OK;
     k_finalize_norm<<<(unsigned)n, kWave, 0, s>>>(partials, parts, norm);
+    return check_launch();
+}
+
+// Finalisation + select in ONE small launch (replaces k_finalize_norm + k_argmin after a scoring launch, and does the
+// cost combine of SearchDDPM.resample_update): wave w finishes particles w, w + nw, ... in the order of k_finalize_norm
+// (bit-identical values), then the block runs the torch.argmin-order select over them.
+// Measured alternative (r02): finishing inside the scoring launch ("last block done", common.h: Tail) costs every short
+// scoring block two dependent memory round trips while it holds its LDS -- 42 us instead of ~25 us at N = 64.
+constexpr int kSelThreads = 1024;
+__global__ __launch_bounds__(kSelThreads) void k_finalize_select(Tail t)
+{
+    __shared__ float s_v[kSelThreads / kWave];
+    __shared__ int64_t s_i[kSelThreads / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = kSelThreads / kWave;
+    ArgMin best{0.0f, -1};
+    constexpr int B = 4;          // particles per wave in flight: their partial loads are issued together (one latency)
+    for (int p0 = wave; p0 < t.n; p0 += nw * B) {
+        double acc[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b] = 0.0;
+        for (int i = lane; i < t.parts; i += kWave) {
+            float v[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int p = min(p0 + b * nw, t.n - 1);             // surplus slots re-read the last particle
+                v[b] = t.partials[(int64_t)p * t.parts + i];
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) acc[b] += (double)v[b];
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int p = p0 + b * nw;
+            if (p >= t.n) break;                                      // wave-uniform
+            double a = acc[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, kWave);
+            float v = t.mode == TAIL_L1SQ ? (float)(a * a * (double)t.l1_scale) : (float)sqrt(a);
+            if (lane == 0) {
+                if (t.raw_out) t.raw_out[p] = v;
+                if (t.prev) {
+                    const float q = t.prev[p];
+                    if (t.potential == POT_MEAN) v = v + q;
+                    else if (t.potential == POT_MIN) v = (v != v || q != q) ? __builtin_nanf("") : fminf(v, q);
+                    else if (t.potential == POT_DIFF) v = v - q;
+                }
+                t.out[p] = v;
+                const ArgMin c{v, p};
+                if (argmin_better(c, best)) best = c;
+            }
+        }
+    }
+    if (!t.best_idx) return;
+    if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) {
+            const ArgMin c{s_v[w], s_i[w]};
+            if (argmin_better(c, best)) best = c;
+        }
+        *t.best_idx = best.i < 0 ? 0 : best.i;
+        if (t.best_val) *t.best_val = best.v;
+    }
+}
+
+int finalize_select(const Tail &t, hipStream_t s)
+{
+    if (t.n == 0) return DPSX_OK;
+    k_finalize_select<<<1, kSelThreads, 0, s>>>(t);
     return check_launch();
 }
 
@@ -365,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const
         acc = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     }
     const float t = block_sum(acc, scratch);
-    if (threadIdx.x == 0) a.partials[p * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0) tail_publish(&a.partials[p * gridDim.x + blockIdx.x], t);
     tail_arrive(a.tail, (int)p);
 }
 

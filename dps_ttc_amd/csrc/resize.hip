@@ -221,7 +221,7 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t);
         tail_arrive(a.tail, plane / a.c);
     }
 }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) a.partials[(int64_t)plane * nblk + blk] = t;
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t);
         tail_arrive(a.tail, plane / a.c);
     }
 }
@@ -668,7 +668,7 @@ static int allow_lds(K kernel, bool &done)
 {
     if (!done) {
         DPSX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
         done = true;
     }
     return DPSX_OK;

@@ -461,7 +461,7 @@ class SearchDDPM(DDPM):
         if self.global_select is not None:
             costs = handle.score(sample, measurement)
             return self.global_select(costs, sample), costs
-        costs, best, _ = handle.score_argmin(sample, measurement)      # norms + select finished by the scoring launch
+        costs, best, _ = handle.score_argmin(sample, measurement)      # norms + select: one small follow-up launch
         self.last_best = best
         return kernels.replicate(sample, best), costs
 

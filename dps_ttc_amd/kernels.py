@@ -190,8 +190,8 @@ class OpHandle:
         return costs
 
     def score_argmin(self, x, y):
-        """-> (costs [N], best int64 scalar, costs[best] [1]) -- the scoring launch finishes the per-particle norms
-        and the torch.argmin-order select itself (gaussian_diffusion.py:626-632); everything stays on the device."""
+        """-> (costs [N], best int64 scalar, costs[best] [1]): scoring launch + one small launch that finishes the
+        per-particle norms and the torch.argmin-order select (gaussian_diffusion.py:626-632); all on the device."""
         x, y = _nchw(f32c(x)), f32c(y)
         n, c, h, w = x.shape
         if n == 0:
@@ -364,11 +364,11 @@ class StepBuffers:
         self.flip = 0
 
 
-def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=True):
-    """K1.  finalize_norm=True (the loop's setting): the launch finishes buf.norm itself -- each particle's last
-    block re-sums the per-tile partial sums in a fixed order -- and step_bwd reads one float per particle.
-    finalize_norm=False: buf.norm is filled by the following step_bwd, whose prologue finalises the partial sums
-    this launch leaves in the workspace.  Same bits either way."""
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False):
+    """K1.  finalize_norm=False (the loop's setting): buf.norm is filled by the following step_bwd, whose prologue
+    finalises the per-tile partial sums this launch leaves in the workspace.  finalize_norm=True: the launch finishes
+    buf.norm itself (each particle's last block re-sums the partials in the same fixed order -- same bits) and
+    step_bwd reads one float per particle; measured at N = 64: K1 +4.8 us, K2 -3.3 us, so the loop does not use it."""
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, x_t.device)
     buf.norm_ready = bool(finalize_norm)

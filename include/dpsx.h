@@ -189,7 +189,7 @@ int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, flo
                    void *workspace, int64_t workspace_bytes, void *stream);
 /* The same scoring with the select fused in (gaussian_diffusion.py:626-631): costs[p] as above, *best_idx_dev =
  * argmin_p costs[p] (torch.argmin: first minimum, NaN counts as the minimum) and, if best_val_dev != NULL, its cost
- * -- finished by the scoring launch itself ("last block done"), no separate reduction / argmin launches. */
+ * -- the per-particle reduction and the select share one small follow-up launch. */
 int dpsx_score_argmin_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs,
                           int64_t *best_idx_dev, float *best_val_dev,
                           int64_t n, int64_t c, int64_t h, int64_t w,

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="fwd,bwd,upd,op,adj,score")
+    ap.add_argument("--norm-in-fwd", action="store_true", help="K1 finishes the norm itself (last block of a particle)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -45,10 +46,11 @@ def main():
     P = bench.P_BYTES
     u = torch.randn((n,) + tuple(y.shape[1:]), device=dev)
     cases = {
-        "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck),
-                (7 + rho) * P),
-        "bwd": (lambda i: (setattr(buf, "norm_ready", False), kernels.step_bwd(handle, buf, y, 0.3, 1, ck)),
-                (4 + rho) * P),     # as in the loop: the norm is finalised from the forward half's partials
+        "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck,
+                                           finalize_norm=args.norm_in_fwd), (7 + rho) * P),
+        # as in the loop: the norm is finalised from the forward half's partials (--norm-in-fwd: by K1's own tail)
+        "bwd": (lambda i: (setattr(buf, "norm_ready", args.norm_in_fwd), kernels.step_bwd(handle, buf, y, 0.3, 1, ck)),
+                (4 + rho) * P),
         "upd": (lambda i: kernels.step_update(buf, ring[i % 2]["g_unet"], ck), 4 * P),
         "op": (lambda i: handle.forward(x_t), (1 + rho) * P),
         "adj": (lambda i: handle.adjoint(u, x=x_t, in_hw=(256, 256)), (1 + rho) * P),

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--unfused", action="store_true", help="separate score / argmin launches (the round-1 sequence)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -37,8 +38,11 @@ def main():
     def step(i, x):
         s = ring[i % 2]
         _, sample = kernels.posterior_fwd(x, s["model_out"], s["noise"], ck, want_x0=False)
-        costs = handle.score(sample, y)
-        return kernels.replicate(sample, kernels.argmin(costs))
+        if args.unfused:
+            costs = handle.score(sample, y)
+            return kernels.replicate(sample, kernels.argmin(costs))
+        costs, best, _ = handle.score_argmin(sample, y)
+        return kernels.replicate(sample, best)
 
     x = x_t
     for i in range(3):

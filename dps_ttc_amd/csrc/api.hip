@@ -162,29 +162,40 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
             op->halo_t = t; op->halo_b = b;
             op->halo_l = (l + 3) / 4 * 4; op->halo_r = (r + 3) / 4 * 4;
         }
-        // vertical runs of <= 4 taps per kernel column, window kept inside [-halo_t, halo_b]
-        std::vector<TapRun> fwd, adj;
+        // vertical runs of 4 or 2 taps per kernel column, window kept inside [-halo_t, halo_b]; four classes
+        // (dx parity x run length) stored one after the other -- see TapRun
+        std::vector<TapRun> cls_f[4], cls_a[4];
         for (int j = 0; j < ks; ++j) {
+            const int dx = j - R, odd = dx & 1;
             int i = 0;
             while (i < ks) {
                 if (kernel_host[i * ks + j] == 0.0f) { ++i; continue; }
+                int k = 0;                                              // consecutive non-zero taps from row i
+                while (i + k < ks && k < 4 && kernel_host[(i + k) * ks + j] != 0.0f) ++k;
+                const int L = k >= 3 ? 4 : 2;
                 const int first = i - R;                               // dy of the run's first tap
-                const int dy0 = std::min(first, op->halo_b - 3);       // shift up so dy0 + 3 <= halo_b (>= -halo_t)
+                const int dy0 = std::min(first, op->halo_b - (L - 1)); // shift up so dy0 + L - 1 <= halo_b (>= -halo_t)
                 TapRun r{};
-                r.dy0 = dy0; r.dx = j - R;
-                for (int q = 0; q < 4; ++q) {
+                r.dy0 = dy0; r.dx = dx;
+                for (int q = 0; q < L; ++q) {
                     const int ii = dy0 + q + R;
                     r.w[q] = (ii >= 0 && ii < ks && ii >= i) ? kernel_host[ii * ks + j] : 0.0f;
                 }
-                fwd.push_back(r);
-                // adjoint (correlation-transpose): V[p][q] = sum w_t u[p - dy_t][q - dx_t] -> negated offsets,
-                // reversed weights, same loop
+                cls_f[2 * odd + (L == 2)].push_back(r);
+                // adjoint (correlation-transpose): V[p][q] = sum w_t u[p - dy_t][q - dx_t] -> negated offsets
+                // (same dx parity), reversed weights, same loop
                 TapRun t{};
-                t.dy0 = -(dy0 + 3); t.dx = -(j - R);
-                for (int q = 0; q < 4; ++q) t.w[q] = r.w[3 - q];
-                adj.push_back(t);
-                i = dy0 + 4 + R;                                       // first row not covered by this run
+                t.dy0 = -(dy0 + L - 1); t.dx = -dx;
+                for (int q = 0; q < L; ++q) t.w[q] = r.w[L - 1 - q];
+                cls_a[2 * odd + (L == 2)].push_back(t);
+                i = dy0 + L + R;                                       // first row not covered by this run
             }
+        }
+        std::vector<TapRun> fwd, adj;
+        for (int c = 0; c < 4; ++c) {
+            op->nrun[c] = (int)cls_f[c].size();
+            fwd.insert(fwd.end(), cls_f[c].begin(), cls_f[c].end());
+            adj.insert(adj.end(), cls_a[c].begin(), cls_a[c].end());
         }
         op->nruns = (int)fwd.size();
         const size_t bytes = std::max<size_t>(fwd.size(), 1) * sizeof(TapRun);

@@ -50,8 +50,10 @@ struct BlurArgs {
     int c, h, w, tiles_x, tiles_y, planes;
     Coefs k;
     // generic taps
-    const TapRun *runs;   // vertical runs of <= 4 taps (forward table, or the adjoint's negated / reversed one)
-    int nruns;
+    // vertical runs of taps (forward table, or the adjoint's negated / reversed one), grouped by class:
+    // [even dx, 4 taps | even dx, 2 taps | odd dx, 4 taps | odd dx, 2 taps]; nrun[k] = runs in class k
+    const TapRun *runs;
+    int nrun[4];
     int dbg;   // phase-ablation mask: 0 unless built with -DDPSX_ABLATION=1 (see blur_sep.h)
     // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
     // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
@@ -255,12 +257,16 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
 #include "blur_sep.h"
 
 // =====================================================================
-// Generic path: list of non-zero taps (dy, dx in [-R, R], weight), read through
-// wave-uniform scalar loads.  thread -> column tid % 64, rows (tid / 64) + 4*i, i < 16:
-// consecutive lanes read consecutive LDS words (conflict-free ds_read_b32).
+// Generic path: list of non-zero taps (dy, dx in [-R, R], weight) grouped into vertical runs, read through
+// wave-uniform scalar loads.  thread -> columns 2 (tid % 32), +1; rows 8 (tid / 32) .. +7:
+// the 32 lanes of a half-wave read 256 consecutive LDS bytes (conflict-free ds_read_b64).
 // LDS: s_in[RH][SW] | 256 floats of scratch
 // =====================================================================
-constexpr int GI = 16;  // outputs per thread: GI consecutive rows of one column
+// 8-byte stores of a lane's column pair need an even row stride and an 8-byte aligned plane
+__device__ __forceinline__ bool regular_out(const BlurArgs &a)
+{
+    return (a.w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0;
+}
 
 // halo of the staged region on each side of the 64 x 64 tile (columns in multiples of 4)
 struct TapGeom {
@@ -338,33 +344,83 @@ __device__ __forceinline__ void load_region_taps_reg(float *s_in, const int SW, 
     }
 }
 
-// acc[i] = sum over the runs of sum_j w[j] * base[(i + dy0 + j) * SW + dx]: the GI + 3 inputs of a run are read once
-// (consecutive lanes -> consecutive LDS words), the run record through wave-uniform scalar loads
-// SWC > 0: the LDS row stride is a compile-time constant, so the GI + 3 reads of a run are one base register plus
-// immediate offsets; SWC == 0: runtime stride.  The next run's record is fetched while this one is processed.
-template <int SWC>
-__device__ __forceinline__ void tap_runs(float (&acc)[GI], const float *base, const int sw_rt, const TapRun *runs,
-                                         const int nruns)
+// ---------------------------------------------------------------- tap loop
+// A lane owns TWO adjacent columns x PRW consecutive rows of the tile.  One run = L vertically consecutive taps of one
+// kernel column: the lane reads its (PRW + L - 1) x 2 window as PRW + L - 1 `ds_read_b64` (8 B per lane: 256 B per LDS
+// clock, twice the rate of the dword reads the round-1 loop sat on -- 19 `ds_read_b32` per 64 FMAs were 38 LDS cycles
+// per wave-run against 32 VALU cycles per CU) and issues PRW * L packed FMAs (pair of columns x broadcast weight).
+// An 8-byte LDS read must be 8-byte aligned, i.e. column (2 cp + dx) even: runs with even dx are processed on the image
+// as staged, then the image is shifted left by one word IN PLACE (no second copy: four blocks per CU stay resident) and
+// the runs with odd dx follow.  Run lengths 4 and 2: a motion path that is mostly horizontal has two vertically adjacent
+// non-zero taps per kernel column (bilinear splat) -- padding those to four wasted half of the FMAs.
+constexpr int PRW = 8;    // rows per lane (x 2 columns = 16 outputs)
+
+template <int L>
+__device__ __forceinline__ void tap_runs_pk(v2f (&acc)[PRW], const float *base, const int SW, const TapRun *runs,
+                                            const int nruns)
 {
-    const int SW = SWC > 0 ? SWC : sw_rt;
-#pragma unroll
-    for (int i = 0; i < GI; ++i) acc[i] = 0.0f;
     if (nruns <= 0) return;
     TapRun r = runs[0];
     for (int t = 0; t < nruns; ++t) {
-        const TapRun nxt = runs[min(t + 1, nruns - 1)];
+        const TapRun nxt = runs[min(t + 1, nruns - 1)];              // next record's scalar loads fly under this run
         const float *p = base + r.dy0 * SW + r.dx;
-        float win[GI + 3];
+        v2f win[PRW + L - 1];
 #pragma unroll
-        for (int m = 0; m < GI + 3; ++m) win[m] = p[m * SW];
+        for (int m = 0; m < PRW + L - 1; ++m) win[m] = *reinterpret_cast<const v2f *>(p + m * SW);
 #pragma unroll
-        for (int i = 0; i < GI; ++i) {
-            acc[i] = fmaf(r.w[0], win[i], acc[i]);
-            acc[i] = fmaf(r.w[1], win[i + 1], acc[i]);
-            acc[i] = fmaf(r.w[2], win[i + 2], acc[i]);
-            acc[i] = fmaf(r.w[3], win[i + 3], acc[i]);
+        for (int q = 0; q < L; ++q) {
+            const v2f w2 = v2f{r.w[q], r.w[q]};
+#pragma unroll
+            for (int i = 0; i < PRW; ++i) acc[i] = __builtin_elementwise_fma(w2, win[i + q], acc[i]);   // v_pk_fma_f32
         }
         r = nxt;
+    }
+}
+
+// s[j] = s[j + 1] over the whole staged image (words: multiple of 4), in place: chunks of NT * 4 units in increasing
+// address order -- a chunk's reads complete (barrier) before its writes, and a later chunk only reads words an earlier
+// one has not written.  After it, an 8-byte read at word (column + dx - 1) yields columns (column + dx, column + dx + 1).
+__device__ __forceinline__ void shift_image_left(float *s, const int words)
+{
+    const int units = words / 4;
+    constexpr int B = 4;
+    for (int u0 = 0; u0 < units; u0 += NT * B) {
+        float4 v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int u = u0 + k * NT + (int)threadIdx.x;
+            if (u < units) {
+                const float *p = s + 4 * u;
+                v[k] = make_float4(p[1], p[2], p[3], 4 * u + 4 < words ? p[4] : 0.0f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int u = u0 + k * NT + (int)threadIdx.x;
+            if (u < units) *reinterpret_cast<float4 *>(s + 4 * u) = v[k];
+        }
+        __syncthreads();
+    }
+}
+
+// all runs of a table on the staged image s_in (row stride SW, even): acc[i] = (column 2cp, 2cp+1) of row r0 + i
+__device__ __forceinline__ void tap_all_runs(v2f (&acc)[PRW], float *s_in, const int SW, const int words,
+                                             const int org, const BlurArgs &a)
+{
+#pragma unroll
+    for (int i = 0; i < PRW; ++i) acc[i] = v2f{0.0f, 0.0f};
+    const TapRun *r = a.runs;
+    tap_runs_pk<4>(acc, s_in + org, SW, r, a.nrun[0]);
+    r += a.nrun[0];
+    tap_runs_pk<2>(acc, s_in + org, SW, r, a.nrun[1]);
+    r += a.nrun[1];
+    if (a.nrun[2] + a.nrun[3] > 0) {                                  // launch-uniform
+        __syncthreads();                                              // every wave is done with the unshifted image
+        shift_image_left(s_in, words);
+        tap_runs_pk<4>(acc, s_in + org - 1, SW, r, a.nrun[2]);
+        r += a.nrun[2];
+        tap_runs_pk<2>(acc, s_in + org - 1, SW, r, a.nrun[3]);
     }
 }
 
@@ -385,33 +441,38 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
         load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
     }
     __syncthreads();
-    const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
-    float acc[GI];
-    tap_runs<0>(acc, s_in + (r0 + g.t) * SW + col + g.l, SW, a.runs, a.nruns);
-    const int ox = w0 + col;
+    const int cp = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * PRW;     // columns 2cp, 2cp+1; rows r0 .. r0 + 7
+    v2f acc[PRW];
+    tap_all_runs(acc, s_in, SW, RH * SW, (r0 + g.t) * SW + 2 * cp + g.l, a);
+    const int ox = w0 + 2 * cp;
     float ss = 0.0f;
     if (RESID && regular) {
-        // full tile: the lane's 16 measurement values are fetched together (one wait), then r = y - A(x0_hat)
+        // full tile: the lane's 8 x 2 measurement values are fetched together (one wait), then r = y - A(x0_hat)
         const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + r0) * a.w + ox);
         const int n = plane / a.c, ch = plane % a.c;
         const float *yp = a.y + ((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * hw + o;
         float *rp = a.out ? a.out + (int64_t)plane * hw + o : nullptr;
-        float yv[GI];
+        v2f yv[PRW];
 #pragma unroll
-        for (int i = 0; i < GI; ++i) yv[i] = yp[(unsigned)(i * a.w)];
+        for (int i = 0; i < PRW; ++i) yv[i] = *reinterpret_cast<const v2f *>(yp + (unsigned)(i * a.w));
 #pragma unroll
-        for (int i = 0; i < GI; ++i) {
-            const float r = yv[i] - acc[i];
-            if (rp) rp[(unsigned)(i * a.w)] = r;
-            if constexpr (POST) ss += r * r;
-            else ss += a.l1 ? fabsf(r) : r * r;
+        for (int i = 0; i < PRW; ++i) {
+            const v2f r = yv[i] - acc[i];
+            if (rp) *reinterpret_cast<v2f *>(rp + (unsigned)(i * a.w)) = r;
+            if constexpr (POST) ss += r.x * r.x + r.y * r.y;
+            else ss += a.l1 ? fabsf(r.x) + fabsf(r.y) : r.x * r.x + r.y * r.y;
         }
-    } else if (ox < a.w) {
+    } else {
 #pragma unroll
-        for (int i = 0; i < GI; ++i) {
+        for (int i = 0; i < PRW; ++i) {
             const int oy = h0 + r0 + i;
-            if constexpr (RESID) ss += resid_epilogue<false>(a, plane, oy, ox, &acc[i], 1);
-            else out_epilogue<false>(a, plane, oy, ox, &acc[i], 0.0f, false, 1);
+            const float two[2] = {acc[i].x, acc[i].y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (ox + e >= a.w) continue;
+                if constexpr (RESID) ss += resid_epilogue<false>(a, plane, oy, ox + e, &two[e], 1);
+                else out_epilogue<false>(a, plane, oy, ox + e, &two[e], 0.0f, false, 1);
+            }
         }
     }
     if constexpr (RESID) {
@@ -446,13 +507,22 @@ __global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, TapGeom g)
         load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
     }
     __syncthreads();
-    const int col = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * GI;
-    float acc[GI];
-    tap_runs<0>(acc, s_in + (r0 + g.t) * SW + col + g.l, SW, a.runs, a.nruns);          // a.runs: the adjoint table
-    const int ox = w0 + col;
-    if (ox < a.w) {
+    const int cp = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * PRW;
+    v2f acc[PRW];
+    tap_all_runs(acc, s_in, SW, RH * SW, (r0 + g.t) * SW + 2 * cp + g.l, a);            // a.runs: the adjoint table
+    const int ox = w0 + 2 * cp;
+    if (regular_out(a) && ox + 1 < a.w && h0 + r0 + PRW <= a.h) {
+        float *gp = a.out + (int64_t)plane * a.h * a.w + (unsigned)((h0 + r0) * a.w + ox);
 #pragma unroll
-        for (int i = 0; i < GI; ++i) out_epilogue<false>(a, plane, h0 + r0 + i, ox, &acc[i], 0.0f, false, 1);
+        for (int i = 0; i < PRW; ++i) *reinterpret_cast<v2f *>(gp + (unsigned)(i * a.w)) = acc[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) {
+            const float two[2] = {acc[i].x, acc[i].y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (ox + e < a.w) out_epilogue<false>(a, plane, h0 + r0 + i, ox + e, &two[e], 0.0f, false, 1);
+        }
     }
 }
 
@@ -674,7 +744,8 @@ static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 
 static void set_taps(const dpsx_op *op, BlurArgs &a)
 {
-    a.runs = static_cast<const TapRun *>(op->d_runs_fwd); a.nruns = op->nruns;
+    a.runs = static_cast<const TapRun *>(op->d_runs_fwd);
+    for (int k = 0; k < 4; ++k) a.nrun[k] = op->nrun[k];
 }
 
 template <bool POST, bool RESID>
@@ -707,7 +778,8 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     c.x = a.x; c.out = scratch;
     fill_geometry(c, a.planes, 1, ph, pw);
     c.src_h = a.h; c.src_w = a.w; c.src_off = r4;
-    c.runs = static_cast<const TapRun *>(op->d_runs_adj); c.nruns = op->nruns;
+    c.runs = static_cast<const TapRun *>(op->d_runs_adj);
+    for (int k = 0; k < 4; ++k) c.nrun[k] = op->nrun[k];
     const TapGeom g{op->halo_b, op->halo_t, op->halo_r, op->halo_l};      // negated offsets: the sides swap
     const size_t lds = taps_lds_bytes(g);
     const bool v2 = vec && aligned16(scratch);

@@ -301,10 +301,10 @@ enum { OP_TAPS = 0, OP_SEP = 1, OP_RESIZE = 2, OP_MASK = 3, OP_IDENT = 4, OP_PHA
 
 constexpr int kMaxRadius = 32;  // kernel side <= 65
 
-// Four vertically consecutive taps of one kernel column (zero padded): out[r][c] += sum_j w[j] * in[r + dy0 + j][c + dx].
-// A lane that owns 16 consecutive output rows of one column reads the 19 inputs of a run once and issues 64 FMAs
-// on them -- 0.3 LDS reads per FMA instead of 1 for a tap at a time (the tap-at-a-time loop sat on the
-// ds_read_b32 bandwidth).  dy0 is shifted so that dy0 .. dy0 + 3 stays inside the staged halo.
+// L (4 or 2) vertically consecutive taps of one kernel column (zero padded): out[r][c] += sum_j w[j] * in[r + dy0 + j][c + dx].
+// A lane that owns 8 rows x 2 adjacent columns reads the (8 + L - 1) x 2 inputs of a run once, as 8-byte LDS reads,
+// and issues 8 L packed FMAs on them (blur.hip: tap_runs_pk).  dy0 is shifted so that dy0 .. dy0 + L - 1 stays inside
+// the staged halo.  Runs are stored grouped by class: [even dx, L=4 | even dx, L=2 | odd dx, L=4 | odd dx, L=2].
 struct TapRun {
     int dy0, dx, pad0, pad1;
     float w[4];
@@ -327,6 +327,7 @@ struct dpsx_op {
     // the same taps as vertical runs of <= 4 (TapRun records): what the tap-list kernels iterate over
     void *d_runs_fwd = nullptr, *d_runs_adj = nullptr;
     int nruns = 0;
+    int nrun[4] = {0, 0, 0, 0};           // runs per class (even/odd dx) x (4/2 taps), in table order
     // halo the tap list actually needs on each side of a tile (rows as they are, columns rounded up to 4): a motion
     // path usually leaves the centre in one direction, so this is about half of radius4 per axis
     int halo_t = 0, halo_b = 0, halo_l = 0, halo_r = 0;

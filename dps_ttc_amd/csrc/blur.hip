@@ -83,7 +83,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 template <bool POST, bool REFLECT, bool VEC>
 __device__ __forceinline__ void load_region(float *s_in, const int SW, const int RH, const int RW,
                                             const int gy0, const int gx0, const int h0, const int w0,
-                                            const BlurArgs &a, const int plane)
+                                            const BlurArgs &a, const int plane, const int tid = threadIdx.x)
 {
     const int h = REFLECT ? a.h : a.src_h, w = REFLECT ? a.w : a.src_w, off = REFLECT ? 0 : a.src_off;
     const int64_t hw = (int64_t)h * w;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void load_region(float *s_in, const int SW, const int
     }
     constexpr int U = VEC ? 4 : 1;
     const int RWu = RW / U;
-    for (int u = threadIdx.x; u < RH * RWu; u += NT) {
+    for (int u = tid; u < RH * RWu; u += NT) {
         const int rr = u / RWu, cu = u - rr * RWu;
         const int gy = gy0 + rr - off, gx = gx0 + cu * U - off;     // coordinates in the source plane
         float val[U];
@@ -262,25 +262,44 @@ __device__ __forceinline__ void out_epilogue(const BlurArgs &a, int plane, int o
 // the 32 lanes of a half-wave read 256 consecutive LDS bytes (conflict-free ds_read_b64).
 // LDS: s_in[RH][SW] | 256 floats of scratch
 // =====================================================================
-// 8-byte stores of a lane's column pair need an even row stride and an 8-byte aligned plane
-__device__ __forceinline__ bool regular_out(const BlurArgs &a)
-{
-    return (a.w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0;
-}
-
 // halo of the staged region on each side of the 64 x 64 tile (columns in multiples of 4)
 struct TapGeom {
     int t, b, l, r;
+    // halo-unit enumeration without integer division (the halo is a run-time quantity here): magic = ceil(2^32 / d)
+    unsigned rwu_magic, side_magic;     // d = region units per row;  d = units per row of the left + right bands
 };
 
-// Region loader of the tap-list kernels for REGULAR geometry (h, w multiples of the tile; 16-byte aligned planes):
-// float4 units wholly inside or outside the image, every load unconditional (load_unit_reg), four units per lane in
-// flight before any is consumed; interior units do S1 and emit x0_hat / sample / gate (POST), the others only
-// recompute x0_hat; units outside the tile read their v / noise from a block of zeros.
-template <bool POST, bool REFLECT>
-__device__ __forceinline__ void load_region_taps_reg(float *s_in, const int SW, const int RH, const int RWu,
-                                                     const TapGeom g, const int h0, const int w0, const BlurArgs &a,
-                                                     const int plane)
+__device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned magic, unsigned d)
+{
+    return d == 1 ? x : __umulhi(x, magic);       // exact for x < 2^16, d <= 128 (checked exhaustively on the host side)
+}
+
+// halo unit hu in [0, H) of a staged region (TH + t + b rows, RWu = (TW + l + r) / 4 units per row) -> (region row,
+// unit column).  [0, (t + b) RWu): the t rows above and the b rows below the tile; the rest: TH rows x (l/4 + r/4) units.
+__device__ __forceinline__ void taps_halo_unit(const TapGeom &g, const int RWu, int hu, int &rr, int &cu)
+{
+    const int band = (g.t + g.b) * RWu;
+    if (hu < band) {
+        const int row = (int)fastdiv((unsigned)hu, g.rwu_magic, (unsigned)RWu);
+        cu = hu - row * RWu;
+        rr = row < g.t ? row : row + TH;
+    } else {
+        const int q = (g.l + g.r) >> 2, v = hu - band;
+        const int row = (int)fastdiv((unsigned)v, g.side_magic, (unsigned)q);
+        const int c = v - row * q;
+        rr = row + g.t;
+        cu = c < (g.l >> 2) ? c : c + TW / 4;
+    }
+}
+
+// Loads-first loader of the tap-list kernels for REGULAR geometry (the recipe of the separable kernel's loader): every
+// lane issues ALL its loads -- 4 interior float4 units x up to 4 streams, then up to NHB halo units x up to 2 streams
+// -- before anything is consumed: one memory round trip per tile instead of one per 1024 units (round 1: 2-4 serialised
+// round trips per tile, with four co-resident blocks in lockstep).  Halo units beyond NHB x 256 (kernels whose path
+// reaches far on several sides) follow in rounds of four.
+template <bool POST, bool REFLECT, int NHB>
+__device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW, const int RWu, const TapGeom g,
+                                                       const int h0, const int w0, const BlurArgs &a, const int plane)
 {
     const int h = REFLECT ? a.h : a.src_h, w = REFLECT ? a.w : a.src_w, off = REFLECT ? 0 : a.src_off;
     const unsigned hw = (unsigned)(h * w);
@@ -294,50 +313,100 @@ __device__ __forceinline__ void load_region_taps_reg(float *s_in, const int SW, 
     } else {
         src = a.x + (int64_t)plane * hw;
     }
-    constexpr int B = 4;
-    const int total = RH * RWu;
+    constexpr int NI = TH * TW / 4 / NT;            // interior units per thread (4)
+    const int H = (g.t + g.b) * RWu + TH * ((g.l + g.r) >> 2);
     const bool noisy = POST && (a.k.add_noise & 1);
-    for (int base = threadIdx.x; base < total; base += NT * B) {
-        float4 xv[B], ev[B], vq[B], zq[B];
-        int rr[B], cu[B];
+    float4 xi[NI], ei[NI], vi[NI], zi[NI], xh[NHB], eh[NHB];
+    // streams with reuse (x, eps: a neighbour's halo is this tile's interior) first, grouped per stream; once-read
+    // streams (v, noise) last and non-temporal
 #pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const int u = min(base + k * NT, total - 1);          // surplus lanes repeat the last unit
-            rr[k] = u / RWu;
-            cu[k] = u - rr[k] * RWu;
-            const int gy = h0 - g.t + rr[k] - off, gx = w0 - g.l + 4 * cu[k] - off;
-            xv[k] = load_unit_reg<REFLECT>(src, gy, gx, h, w);
-            if constexpr (POST) {
-                ev[k] = load_unit_reg<true>(eps, gy, gx, h, w);
-                const bool interior = rr[k] >= g.t && rr[k] < g.t + TH && 4 * cu[k] >= g.l && 4 * cu[k] < g.l + TW;
-                const unsigned o = (unsigned)(gy * w + gx);
-                vq[k] = *reinterpret_cast<const float4 *>((noisy && interior) ? vv + o : g_zero_unit);
-                zq[k] = *reinterpret_cast<const float4 *>((noisy && interior) ? zz + o : g_zero_unit);
-            }
+    for (int pass = 0; pass < (POST ? 2 : 1); ++pass) {
+        const float *p = pass ? eps : src;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+            const float4 v = load_unit_reg<REFLECT || POST>(p, h0 + row - off, w0 + 4 * cu - off, h, w);
+            if (pass) ei[k] = v; else xi[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NHB; ++k) {
+            const int hu = min((int)threadIdx.x + k * NT, H - 1);        // surplus lanes repeat the last unit
+            int rr, cu;
+            taps_halo_unit(g, RWu, max(hu, 0), rr, cu);
+            const float4 v = load_unit_reg<REFLECT || POST>(p, h0 - g.t + rr - off, w0 - g.l + 4 * cu - off, h, w);
+            if (pass) eh[k] = v; else xh[k] = v;
+        }
+    }
+    if constexpr (POST) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+            const unsigned o = (unsigned)((h0 + row) * w + w0 + 4 * cu);
+            vi[k] = ld_stream(noisy ? vv + o : g_zero_unit, true);
+            zi[k] = ld_stream(noisy ? zz + o : g_zero_unit, true);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load above issues before the first use below
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
+        float4 val = xi[k];
+        if constexpr (POST) {
+            bool b0, b1, b2, b3;
+            float4 x0, sm;
+            x0.x = post_x0(xi[k].x, ei[k].x, a.k, b0);
+            x0.y = post_x0(xi[k].y, ei[k].y, a.k, b1);
+            x0.z = post_x0(xi[k].z, ei[k].z, a.k, b2);
+            x0.w = post_x0(xi[k].w, ei[k].w, a.k, b3);
+            sm.x = post_sample(xi[k].x, x0.x, vi[k].x, zi[k].x, a.k);
+            sm.y = post_sample(xi[k].y, x0.y, vi[k].y, zi[k].y, a.k);
+            sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
+            sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
+            const int64_t o = (int64_t)plane * hw + (unsigned)((h0 + row) * w + w0 + 4 * cu);
+            *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+            *reinterpret_cast<float4 *>(a.sample + o) = sm;
+            *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
+            val = x0;
+        }
+        *reinterpret_cast<float4 *>(s_in + (g.t + row) * SW + g.l + 4 * cu) = val;
+    }
+#pragma unroll
+    for (int k = 0; k < NHB; ++k) {
+        const int hu = threadIdx.x + k * NT;
+        if (hu >= H) continue;
+        int rr, cu;
+        taps_halo_unit(g, RWu, hu, rr, cu);
+        float4 val = xh[k];
+        if constexpr (POST) {
+            bool b;
+            val.x = post_x0(xh[k].x, eh[k].x, a.k, b);
+            val.y = post_x0(xh[k].y, eh[k].y, a.k, b);
+            val.z = post_x0(xh[k].z, eh[k].z, a.k, b);
+            val.w = post_x0(xh[k].w, eh[k].w, a.k, b);
+        }
+        *reinterpret_cast<float4 *>(s_in + rr * SW + 4 * cu) = val;
+    }
+    // far-reaching kernels: the remaining halo units, four per lane in flight
+    for (int base = NHB * NT + threadIdx.x; base < H; base += 4 * NT) {
+        float4 xv[4], ev[4];
+        int rr[4], cu[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            taps_halo_unit(g, RWu, min(base + k * NT, H - 1), rr[k], cu[k]);
+            xv[k] = load_unit_reg<REFLECT || POST>(src, h0 - g.t + rr[k] - off, w0 - g.l + 4 * cu[k] - off, h, w);
+            if constexpr (POST) ev[k] = load_unit_reg<true>(eps, h0 - g.t + rr[k], w0 - g.l + 4 * cu[k], h, w);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < B; ++k) {
-            if (base + k * NT >= total) break;
+        for (int k = 0; k < 4; ++k) {
+            if (base + k * NT >= H) break;
             float4 val = xv[k];
             if constexpr (POST) {
-                bool b0, b1, b2, b3;
-                val.x = post_x0(xv[k].x, ev[k].x, a.k, b0);
-                val.y = post_x0(xv[k].y, ev[k].y, a.k, b1);
-                val.z = post_x0(xv[k].z, ev[k].z, a.k, b2);
-                val.w = post_x0(xv[k].w, ev[k].w, a.k, b3);
-                const bool interior = rr[k] >= g.t && rr[k] < g.t + TH && 4 * cu[k] >= g.l && 4 * cu[k] < g.l + TW;
-                if (interior) {
-                    float4 sm;
-                    sm.x = post_sample(xv[k].x, val.x, vq[k].x, zq[k].x, a.k);
-                    sm.y = post_sample(xv[k].y, val.y, vq[k].y, zq[k].y, a.k);
-                    sm.z = post_sample(xv[k].z, val.z, vq[k].z, zq[k].z, a.k);
-                    sm.w = post_sample(xv[k].w, val.w, vq[k].w, zq[k].w, a.k);
-                    const int64_t o = (int64_t)plane * hw + (unsigned)((h0 - g.t + rr[k]) * w + w0 - g.l + 4 * cu[k]);
-                    *reinterpret_cast<float4 *>(a.x0_hat + o) = val;
-                    *reinterpret_cast<float4 *>(a.sample + o) = sm;
-                    *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
-                }
+                bool b;
+                val.x = post_x0(xv[k].x, ev[k].x, a.k, b);
+                val.y = post_x0(xv[k].y, ev[k].y, a.k, b);
+                val.z = post_x0(xv[k].z, ev[k].z, a.k, b);
+                val.w = post_x0(xv[k].w, ev[k].w, a.k, b);
             }
             *reinterpret_cast<float4 *>(s_in + rr[k] * SW + 4 * cu[k]) = val;
         }
@@ -346,107 +415,156 @@ __device__ __forceinline__ void load_region_taps_reg(float *s_in, const int SW, 
 
 // ---------------------------------------------------------------- tap loop
 // A lane owns TWO adjacent columns x PRW consecutive rows of the tile.  One run = L vertically consecutive taps of one
-// kernel column: the lane reads its (PRW + L - 1) x 2 window as PRW + L - 1 `ds_read_b64` (8 B per lane: 256 B per LDS
-// clock, twice the rate of the dword reads the round-1 loop sat on -- 19 `ds_read_b32` per 64 FMAs were 38 LDS cycles
-// per wave-run against 32 VALU cycles per CU) and issues PRW * L packed FMAs (pair of columns x broadcast weight).
-// An 8-byte LDS read must be 8-byte aligned, i.e. column (2 cp + dx) even: runs with even dx are processed on the image
-// as staged, then the image is shifted left by one word IN PLACE (no second copy: four blocks per CU stay resident) and
-// the runs with odd dx follow.  Run lengths 4 and 2: a motion path that is mostly horizontal has two vertically adjacent
-// non-zero taps per kernel column (bilinear splat) -- padding those to four wasted half of the FMAs.
+// kernel column: the lane reads its (PRW + L - 1) x 2 window once and issues PRW * L packed FMAs on it (pair of columns
+// x broadcast weight: v_pk_fma_f32 keeps a SIMD's FMA pipe full from ONE wave, which is what lets half of a
+// workgroup's waves do nothing but load -- below).  Window reads: 8 bytes per lane as `ds_read_b64` when the column
+// offset is even (256 B per LDS clock, twice the rate of the dword reads the round-1 loop sat on: 19 `ds_read_b32` per
+// 64 FMAs were 38 LDS cycles per wave-run against 32 VALU cycles per CU), as `ds_read2_b32` when it is odd (an 8-byte
+// LDS read must be 8-byte aligned).  SWC > 0: compile-time row stride, so every read of a run is one base register plus
+// an immediate offset (one address computation per run instead of one per row -- 11 v_add per 32 v_pk_fma otherwise).
+// Run lengths 4 and 2: a mostly horizontal motion path has two vertically adjacent non-zero taps per kernel column
+// (bilinear splat); padding those to four wasted half of the FMAs.
 constexpr int PRW = 8;    // rows per lane (x 2 columns = 16 outputs)
 
-template <int L>
-__device__ __forceinline__ void tap_runs_pk(v2f (&acc)[PRW], const float *base, const int SW, const TapRun *runs,
-                                            const int nruns)
+struct RunClip {          // zero-extended sources (adjoint): the source plane's extent in tile coordinates, for run skipping
+    int row_lo, row_hi, col_lo, col_hi;      // source rows / columns [lo, hi) relative to the wave's first row / tile column 0
+};
+
+// Run records are read-only for the whole launch: fetched through the constant address space so that the wave-uniform
+// index turns into scalar loads (s_load_dwordx8 into SGPRs; weights then feed v_pk_fma_f32 as scalar operands).  Through
+// the generic pointer the compiler must assume the kernel's own stores may alias the table and falls back to vector
+// loads plus per-lane selects -- 2.5x the VALU instructions of the FMAs themselves (measured: SQ_INSTS_VALU).
+typedef const __attribute__((address_space(4))) TapRun *ConstRuns;
+__device__ __forceinline__ TapRun load_run(const TapRun *runs, int i)
 {
-    if (nruns <= 0) return;
-    TapRun r = runs[0];
-    for (int t = 0; t < nruns; ++t) {
-        const TapRun nxt = runs[min(t + 1, nruns - 1)];              // next record's scalar loads fly under this run
-        const float *p = base + r.dy0 * SW + r.dx;
-        v2f win[PRW + L - 1];
+    const ConstRuns c = (ConstRuns)(runs);
+    TapRun r;
+    r.dy0 = c[i].dy0; r.dx = c[i].dx; r.pad0 = 0; r.pad1 = 0;
+    r.w[0] = c[i].w[0]; r.w[1] = c[i].w[1]; r.w[2] = c[i].w[2]; r.w[3] = c[i].w[3];
+    return r;
+}
+
+template <bool CLIP, int L>
+__device__ __forceinline__ bool run_live(const TapRun &r, const RunClip &clip)
+{
+    if constexpr (!CLIP) return true;
+    // wave-uniform: the window rows [dy0, dy0 + 15 + L - 1] / columns [dx, dx + 63] of this wave miss the source
+    // plane entirely (a ring tile of the padded domain): every product would be with a staged zero
+    return r.dy0 + 2 * PRW + L - 2 >= clip.row_lo && r.dy0 < clip.row_hi && r.dx + TW - 1 >= clip.col_lo &&
+           r.dx < clip.col_hi;
+}
+
+// One run on the lane's window.  Even dx: (PRW + L - 1) 8-byte reads, PRW * L packed FMAs.  Odd dx: the pair of columns
+// (2cp + dx, 2cp + dx + 1) straddles two aligned 8-byte words, so the lane reads both -- (x0, x1) at 2cp + dx - 1 and
+// (x2, x3) at 2cp + dx + 1 -- and uses x1 for its left column, x2 for its right one: 2 (PRW + L - 1) reads and
+// 2 PRW L scalar FMAs (the same FMA-pipe time as the packed form; `ds_read2_b32` on the odd address would cost the same
+// LDS cycles on paper but runs into 2-way bank conflicts: 32 lanes x stride-2 dwords on 32 banks -- measured, 33 % of all
+// LDS cycles).  The reads are volatile so that the backend does not fuse two of them into one `ds_read2_b64`, which
+// moves 128 B per LDS clock where two `ds_read_b64` move 256.
+typedef const volatile __attribute__((address_space(3))) v2f *LdsPair;     // explicit LDS pointer: volatile must not demote the read to a flat load
+
+template <int L, bool ODD, int SWC>
+__device__ __forceinline__ void run_apply(v2f (&acc)[PRW], const float *base, const int SW, const TapRun &r)
+{
+    const float *p = base + r.dy0 * SW + r.dx - (ODD ? 1 : 0);
+    v2f wa[PRW + L - 1], wb[ODD ? PRW + L - 1 : 1];
 #pragma unroll
-        for (int m = 0; m < PRW + L - 1; ++m) win[m] = *reinterpret_cast<const v2f *>(p + m * SW);
+    for (int m = 0; m < PRW + L - 1; ++m) {
+        wa[m] = *(LdsPair)(p + m * SW);
+        if constexpr (ODD) wb[m] = *(LdsPair)(p + m * SW + 2);
+    }
 #pragma unroll
-        for (int q = 0; q < L; ++q) {
+    for (int q = 0; q < L; ++q) {
+        if constexpr (ODD) {
+#pragma unroll
+            for (int i = 0; i < PRW; ++i) {
+                acc[i].x = fmaf(r.w[q], wa[i + q].y, acc[i].x);
+                acc[i].y = fmaf(r.w[q], wb[i + q].x, acc[i].y);
+            }
+        } else {
             const v2f w2 = v2f{r.w[q], r.w[q]};
 #pragma unroll
-            for (int i = 0; i < PRW; ++i) acc[i] = __builtin_elementwise_fma(w2, win[i + q], acc[i]);   // v_pk_fma_f32
+            for (int i = 0; i < PRW; ++i) acc[i] = __builtin_elementwise_fma(w2, wa[i + q], acc[i]);   // v_pk_fma_f32
         }
+    }
+}
+
+// The runs of one class.  Latency is hidden by the four or more waves that share a SIMD (one workgroup per tile, four
+// per CU), not by pipelining inside a wave: a hand-pipelined form (next run's window loaded before this run's FMAs, two
+// register sets) cost 44 register moves per pair of runs and was slower.  The next record's scalar loads are issued a
+// run ahead.
+template <int L, bool ODD, int SWC, bool CLIP>
+__device__ __forceinline__ void tap_runs_pk(v2f (&acc)[PRW], const float *base, const int sw_rt, const TapRun *runs,
+                                            const int nruns, const RunClip clip)
+{
+    const int SW = SWC > 0 ? SWC : sw_rt;
+    if (nruns <= 0) return;
+    TapRun r = load_run(runs, 0);
+    for (int t = 0; t < nruns; ++t) {
+        const TapRun nxt = load_run(runs, min(t + 1, nruns - 1));
+        if (run_live<CLIP, L>(r, clip)) run_apply<L, ODD, SWC>(acc, base, SW, r);
         r = nxt;
     }
 }
 
-// s[j] = s[j + 1] over the whole staged image (words: multiple of 4), in place: chunks of NT * 4 units in increasing
-// address order -- a chunk's reads complete (barrier) before its writes, and a later chunk only reads words an earlier
-// one has not written.  After it, an 8-byte read at word (column + dx - 1) yields columns (column + dx, column + dx + 1).
-__device__ __forceinline__ void shift_image_left(float *s, const int words)
-{
-    const int units = words / 4;
-    constexpr int B = 4;
-    for (int u0 = 0; u0 < units; u0 += NT * B) {
-        float4 v[B];
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const int u = u0 + k * NT + (int)threadIdx.x;
-            if (u < units) {
-                const float *p = s + 4 * u;
-                v[k] = make_float4(p[1], p[2], p[3], 4 * u + 4 < words ? p[4] : 0.0f);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const int u = u0 + k * NT + (int)threadIdx.x;
-            if (u < units) *reinterpret_cast<float4 *>(s + 4 * u) = v[k];
-        }
-        __syncthreads();
-    }
-}
-
-// all runs of a table on the staged image s_in (row stride SW, even): acc[i] = (column 2cp, 2cp+1) of row r0 + i
-__device__ __forceinline__ void tap_all_runs(v2f (&acc)[PRW], float *s_in, const int SW, const int words,
-                                             const int org, const BlurArgs &a)
+// all runs of a table on the staged image s_in (row stride SW, even): acc[i] = columns (2cp, 2cp+1) of row r0 + i
+template <int SWC, bool CLIP>
+__device__ __forceinline__ void tap_all_runs(v2f (&acc)[PRW], const float *s_in, const int SW, const int org,
+                                             const BlurArgs &a, const RunClip clip)
 {
 #pragma unroll
     for (int i = 0; i < PRW; ++i) acc[i] = v2f{0.0f, 0.0f};
     const TapRun *r = a.runs;
-    tap_runs_pk<4>(acc, s_in + org, SW, r, a.nrun[0]);
+    tap_runs_pk<4, false, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[0], clip);
     r += a.nrun[0];
-    tap_runs_pk<2>(acc, s_in + org, SW, r, a.nrun[1]);
+    tap_runs_pk<2, false, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[1], clip);
     r += a.nrun[1];
-    if (a.nrun[2] + a.nrun[3] > 0) {                                  // launch-uniform
-        __syncthreads();                                              // every wave is done with the unshifted image
-        shift_image_left(s_in, words);
-        tap_runs_pk<4>(acc, s_in + org - 1, SW, r, a.nrun[2]);
-        r += a.nrun[2];
-        tap_runs_pk<2>(acc, s_in + org - 1, SW, r, a.nrun[3]);
-    }
+    tap_runs_pk<4, true, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[2], clip);
+    r += a.nrun[2];
+    tap_runs_pk<2, true, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[3], clip);
 }
 
-template <bool POST, bool RESID, bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
+// ---------------------------------------------------------------- kernels
+// One workgroup (4 waves) per 64 x 64 tile, four or more resident per CU: loads-first stage, tap loop, epilogue.
+// MODE 0: plain A x -> out;  1: residual y - A x (+ out if non-null) and the per-tile sum (score / fused forward);
+// MODE 2: correlation-transpose of the zero-extended cotangent on the padded domain -> out (adjoint, first launch).
+// Measured and dropped (r02): a persistent wave-specialised form (4 loader + 4 compute waves per workgroup, two LDS
+// images, one barrier per tile) -- 144 us for the fused forward against 122 for this structure before the loads-first
+// stage: with half the waves loading, two compute waves per SIMD do not cover the tap loop's LDS and scalar-load
+// latencies (LDS reads and scalar loads share one counter, so a run record's wait drains the window reads too).
+template <bool POST, int MODE, bool VEC, int SWC>
+__global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
 {
-    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = RW + 4;
+    constexpr bool RESID = MODE == 1, REFLECT = MODE != 2;
+    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = SWC > 0 ? SWC : RW;
     extern __shared__ __align__(16) float lds[];
     float *s_in = lds, *s_red = lds + RH * SW;
     int plane, ty, tx;
     if (!block_to_tile(a, plane, ty, tx)) return;
     const int h0 = ty * TH, w0 = tx * TW;
-    const bool regular = VEC && a.h % TH == 0 && a.w % TW == 0 && max(g.t, g.b) < a.h && max(g.l, g.r) < a.w;
+    bool regular;
+    if constexpr (REFLECT) regular = VEC && a.h % TH == 0 && a.w % TW == 0 && max(g.t, g.b) < a.h && max(g.l, g.r) < a.w;
+    else regular = VEC && a.src_w % 4 == 0 && a.src_off % 4 == 0;   // the SOURCE decides whether a unit is wholly in or out
     if constexpr (VEC) {
-        if (regular) load_region_taps_reg<POST, true>(s_in, SW, RH, RW / 4, g, h0, w0, a, plane);
-        else load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+        if (regular) load_region_taps_first<POST, REFLECT, 4>(s_in, SW, RW / 4, g, h0, w0, a, plane);
+        else load_region<POST, REFLECT, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
     } else {
-        load_region<POST, true, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
+        load_region<POST, REFLECT, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
     }
     __syncthreads();
-    const int cp = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * PRW;     // columns 2cp, 2cp+1; rows r0 .. r0 + 7
+    const int tid = threadIdx.x;
+    const int cp = tid & 31, r0 = (tid >> 5) * PRW;       // columns 2cp, 2cp+1; rows r0 .. r0 + 7
+    RunClip clip{0, 0, 0, 0};
+    if constexpr (!REFLECT) {
+        const int wr0 = h0 + ((tid >> 6) * 2 * PRW);      // first row of this WAVE, in domain coordinates
+        clip = RunClip{a.src_off - wr0, a.src_off + a.src_h - wr0, a.src_off - w0, a.src_off + a.src_w - w0};
+    }
     v2f acc[PRW];
-    tap_all_runs(acc, s_in, SW, RH * SW, (r0 + g.t) * SW + 2 * cp + g.l, a);
+    tap_all_runs<SWC, !REFLECT>(acc, s_in, SW, (r0 + g.t) * SW + 2 * cp + g.l, a, clip);
     const int ox = w0 + 2 * cp;
+    const bool full = VEC && a.h % TH == 0 && a.w % TW == 0;
     float ss = 0.0f;
-    if (RESID && regular) {
+    if (RESID && full) {
         // full tile: the lane's 8 x 2 measurement values are fetched together (one wait), then r = y - A(x0_hat)
         const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + r0) * a.w + ox);
         const int n = plane / a.c, ch = plane % a.c;
@@ -462,6 +580,11 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
             if constexpr (POST) ss += r.x * r.x + r.y * r.y;
             else ss += a.l1 ? fabsf(r.x) + fabsf(r.y) : r.x * r.x + r.y * r.y;
         }
+    } else if (!RESID && (a.w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0 && ox + 1 < a.w &&
+               h0 + r0 + PRW <= a.h) {
+        float *gp = a.out + (int64_t)plane * a.h * a.w + (unsigned)((h0 + r0) * a.w + ox);
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) *reinterpret_cast<v2f *>(gp + (unsigned)(i * a.w)) = acc[i];
     } else {
 #pragma unroll
         for (int i = 0; i < PRW; ++i) {
@@ -479,50 +602,6 @@ __global__ __launch_bounds__(NT) void k_blur_taps_fwd(BlurArgs a, TapGeom g)
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t);
         tail_arrive(a.tail, plane / a.c);
-    }
-}
-
-// Adjoint of the tap-list operator in two launches (deterministic, no atomics):
-//   k_blur_taps_corrT : V = C^T u on the whole PADDED domain (h + 2 R4) x (w + 2 R4): the correlation-transpose
-//                       of the zero-extended cotangent, V[p][q] = sum_t w_t * u_z[p - dy_t][q - dx_t].  Uniform
-//                       work for every tile -- no border special cases in the tap loop.
-//   k_blur_fold       : reflection_pad2d backward, g[i][j] = sum over the <= 3 x 3 padded positions that
-//                       ReflectionPad maps onto (i, j), fused with the clamp gate / -b*coef epilogue of the step.
-template <bool VEC>
-__global__ __launch_bounds__(NT) void k_blur_taps_corrT(BlurArgs a, TapGeom g)
-{
-    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = RW + 4;
-    extern __shared__ __align__(16) float lds[];
-    float *s_in = lds;
-    int plane, ty, tx;
-    if (!block_to_tile(a, plane, ty, tx)) return;
-    const int h0 = ty * TH, w0 = tx * TW;
-    // the padded domain need not be a multiple of the tile, but the SOURCE plane (zero-extended) decides whether a
-    // unit is wholly inside or outside: src_w and src_off multiples of 4 are enough for the unconditional loader
-    const bool regular = VEC && a.src_w % 4 == 0 && a.src_off % 4 == 0;
-    if constexpr (VEC) {
-        if (regular) load_region_taps_reg<false, false>(s_in, SW, RH, RW / 4, g, h0, w0, a, plane);
-        else load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
-    } else {
-        load_region<false, false, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
-    }
-    __syncthreads();
-    const int cp = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * PRW;
-    v2f acc[PRW];
-    tap_all_runs(acc, s_in, SW, RH * SW, (r0 + g.t) * SW + 2 * cp + g.l, a);            // a.runs: the adjoint table
-    const int ox = w0 + 2 * cp;
-    if (regular_out(a) && ox + 1 < a.w && h0 + r0 + PRW <= a.h) {
-        float *gp = a.out + (int64_t)plane * a.h * a.w + (unsigned)((h0 + r0) * a.w + ox);
-#pragma unroll
-        for (int i = 0; i < PRW; ++i) *reinterpret_cast<v2f *>(gp + (unsigned)(i * a.w)) = acc[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < PRW; ++i) {
-            const float two[2] = {acc[i].x, acc[i].y};
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (ox + e < a.w) out_epilogue<false>(a, plane, h0 + r0 + i, ox + e, &two[e], 0.0f, false, 1);
-        }
     }
 }
 
@@ -638,10 +717,6 @@ static inline size_t sep_lds_bytes(int rr)
 {
     return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes;
 }
-static inline size_t taps_lds_bytes(const TapGeom &g)
-{
-    return (size_t)((TH + g.t + g.b) * (TW + g.l + g.r + 4)) * 4 + kScratchBytes;
-}
 
 static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int64_t w)
 {
@@ -748,14 +823,48 @@ static void set_taps(const dpsx_op *op, BlurArgs &a)
     for (int k = 0; k < 4; ++k) a.nrun[k] = op->nrun[k];
 }
 
+// compile-time LDS row-stride classes of the 16-byte-load variants (0 = runtime stride, the scalar-load variants)
+static inline int taps_swc(const TapGeom &g, bool vec)
+{
+    const int rw = TW + g.l + g.r;
+    return !vec ? 0 : (rw <= 96 ? 96 : 128);
+}
+static inline size_t taps_lds(const TapGeom &g, int swc)
+{
+    const int rh = TH + g.t + g.b, sw = swc > 0 ? swc : TW + g.l + g.r;
+    return ((size_t)rh * sw) * 4 + kScratchBytes;
+}
+static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+
+static TapGeom make_geom(int t, int b, int l, int r)
+{
+    TapGeom g{t, b, l, r, 0u, 0u};
+    g.rwu_magic = magic_of((unsigned)((TW + l + r) / 4));
+    g.side_magic = magic_of((unsigned)((l + r) / 4));
+    return g;
+}
+
+template <bool POST, int MODE, bool VEC, int SWC>
+static int launch_taps_k(const BlurArgs &a, const TapGeom &g, hipStream_t s)
+{
+    const size_t lds = taps_lds(g, SWC);
+    DPSX_LAUNCH((k_blur_taps<POST, MODE, VEC, SWC>), grid_blocks(a), lds, s, a, g);
+}
+
+template <bool POST, int MODE>
+static int launch_taps(const BlurArgs &a, const TapGeom &g, bool vec, hipStream_t s)
+{
+    if (!vec) return launch_taps_k<POST, MODE, false, 0>(a, g, s);
+    if (taps_swc(g, true) == 96) return launch_taps_k<POST, MODE, true, 96>(a, g, s);
+    return launch_taps_k<POST, MODE, true, 128>(a, g, s);
+}
+
 template <bool POST, bool RESID>
 static int launch_taps_fwd(const dpsx_op *op, BlurArgs a, bool vec, hipStream_t s)
 {
     set_taps(op, a);
-    const TapGeom g{op->halo_t, op->halo_b, op->halo_l, op->halo_r};
-    const size_t lds = taps_lds_bytes(g);
-    if (vec) DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, true>), grid_blocks(a), lds, s, a, g);
-    DPSX_LAUNCH((k_blur_taps_fwd<POST, RESID, false>), grid_blocks(a), lds, s, a, g);
+    const TapGeom g = make_geom(op->halo_t, op->halo_b, op->halo_l, op->halo_r);
+    return launch_taps<POST, RESID ? 1 : 0>(a, g, vec, s);
 }
 
 int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h, int64_t w)
@@ -780,16 +889,11 @@ static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scrat
     c.src_h = a.h; c.src_w = a.w; c.src_off = r4;
     c.runs = static_cast<const TapRun *>(op->d_runs_adj);
     for (int k = 0; k < 4; ++k) c.nrun[k] = op->nrun[k];
-    const TapGeom g{op->halo_b, op->halo_t, op->halo_r, op->halo_l};      // negated offsets: the sides swap
-    const size_t lds = taps_lds_bytes(g);
+    const TapGeom g = make_geom(op->halo_b, op->halo_t, op->halo_r, op->halo_l);      // negated offsets: the sides swap
     const bool v2 = vec && aligned16(scratch);
     {
-        static bool done_v = false, done_s = false;
-        int rc = v2 ? allow_lds(&k_blur_taps_corrT<true>, lds, done_v) : allow_lds(&k_blur_taps_corrT<false>, lds, done_s);
+        int rc = launch_taps<false, 2>(c, g, v2, s);
         if (rc != DPSX_OK) return rc;
-        if (v2) hipLaunchKernelGGL(k_blur_taps_corrT<true>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, g);
-        else hipLaunchKernelGGL(k_blur_taps_corrT<false>, dim3(grid_blocks(c)), dim3(NT), lds, s, c, g);
-        if ((rc = check_launch()) != DPSX_OK) return rc;
     }
     // 2. fold + epilogue
     FoldArgs f{};

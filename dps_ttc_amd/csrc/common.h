@@ -211,7 +211,7 @@ __device__ __forceinline__ void tail_publish(float *p, float v)      // a partia
 __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
 {
     if (!t.counters) return;                                    // launch-uniform
-    __shared__ int s_tail[49];                                  // flag + 16 x (value, index lo, index hi)
+    __shared__ __attribute__((aligned(16))) int s_tail[52];     // flag + 16 x (value, index lo, index hi); 16-byte multiple (G17)
     int *s_flag = s_tail;
     if (threadIdx.x == 0) {                                     // the thread that published the partial
         __builtin_amdgcn_s_waitcnt(0);                          // ... whose write-through store has completed
@@ -284,6 +284,34 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
         }
         *t.best_idx = best.i < 0 ? 0 : best.i;
         if (t.best_val) *t.best_val = best.v;
+    }
+}
+
+// The same arrival for kernels whose waves have different roles: called by ALL 64 lanes of ONE wave, whose lane 0
+// published the partial.  Per-particle value only (no select).
+__device__ __forceinline__ void tail_arrive_wave(const Tail &t, int particle)
+{
+    if (!t.counters) return;
+    int last = 0;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned prev = __hip_atomic_fetch_add(&t.counters[1 + particle], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == (unsigned)t.blocks_per_particle - 1u;
+        if (last) __hip_atomic_store(&t.counters[1 + particle], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last = __shfl(last, 0, kWave);
+    if (!last) return;                                          // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double acc = 0.0;
+    const float *pp = t.partials + (int64_t)particle * t.parts;
+    for (int i = threadIdx.x & (kWave - 1); i < t.parts; i += kWave) acc += (double)tail_ld(pp + i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        const float v = t.mode == TAIL_L1SQ ? (float)(acc * acc * (double)t.l1_scale) : (float)sqrt(acc);
+        if (t.raw_out) t.raw_out[particle] = v;
+        __hip_atomic_store(t.out + particle, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -915,3 +915,33 @@ def test_in_launch_reduction_sees_fresh_partials(K, name, hw, n):
         got = buf.norm.clone()
         ref = torch.linalg.norm((y - op.forward(buf.x0_hat, **fkw)).reshape(n, -1).double(), dim=-1)
         assert rel_l2(host(got), ref.cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("hw", [(128, 192), (192, 128), (256, 256), (128, 128)])
+@pytest.mark.parametrize("kind,seed", [("motion", 2), ("motion", 7), ("gauss_taps", 0), ("wide", 0)])
+def test_taps_regular_multi_tile(K, oracle, kind, seed, hw):
+    """tap-list operator on regular multi-tile images (loads-first stage, clipped ring tiles of the padded-domain
+    adjoint) for kernels of different reach -- a short path, the 25 x 25 Gaussian as a tap list (reach 12), and a
+    kernel that reaches 29 px on every side -- against the oracle, plus <A x, u> = <x, A^T u>"""
+    rng = np.random.RandomState(seed + hw[0])
+    if kind == "motion":
+        k2 = synthetic_motion_kernel(61, seed)
+    elif kind == "gauss_taps":
+        k2 = oracle.tables.gaussian_kernel2d(61, 3.0).astype(np.float32)
+    else:
+        k2 = np.zeros((61, 61), dtype=np.float32)
+        idx = rng.randint(1, 60, size=(40, 2))
+        k2[idx[:, 0], idx[:, 1]] = rng.rand(40).astype(np.float32)
+        k2[1, 1] = k2[59, 59] = k2[1, 59] = k2[59, 1] = 0.3
+        k2 /= k2.sum()
+    h = K.OpHandle.blur(k2, DEV, force_taps=True)
+    assert h.kind == K._lib.KIND_TAPS
+    x = rng.randn(2, 3, *hw).astype(np.float32)
+    u = rng.randn(2, 3, *hw).astype(np.float32)
+    y = h.forward(dev(x))
+    g = h.adjoint(dev(u), in_hw=hw)
+    assert rel_l2(host(y), oracle.blur_fwd(x, k2)) < TOL
+    assert rel_l2(host(g), oracle.blur_adj(u, k2)) < TOL
+    lhs = (y.double() * dev(u).double()).sum().item()
+    rhs = (dev(x).double() * g.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), np.sqrt(float(y.numel())))

@@ -612,7 +612,8 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 // that finishes costs[p] and, when asked, the combine with the previous costs and the argmin over all particles.
 static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, int l1, const float *prev,
                       int potential, float *raw_out, float *costs, int64_t *best_idx, float *best_val, int64_t n,
-                      int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
+                      int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream,
+                      float *replicate_to = nullptr)
 {
     int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
@@ -660,7 +661,33 @@ static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, 
     default: return DPSX_EUNSUPPORTED;
     }
     if (rc != DPSX_OK) return rc;
+    if (replicate_to) {
+        // search step: costs + select, then dst[p] = x[best].  Measured and dropped: both in one launch (every block
+        // redoing the small reduction out of LDS before it copies its slice): 92.5 us per step against 89.3, N = 64.
+        if ((rc = finalize_select(fin, s)) != DPSX_OK) return rc;
+        return gather_f32(x, best_idx, replicate_to, n, n, chw, true, s);
+    }
     return finalize_select(fin, s);
+}
+
+int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise, const float *y,
+                         int64_t y_n, float *sample, float *costs, int64_t *best_idx_dev, float *best_val_dev,
+                         float *x_next, int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
+                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_geom(op, n, c, h, w);
+    if (rc != DPSX_OK) return rc;
+    if (!x_t || !model_out || !y || !sample || !costs || !best_idx_dev || !coefs_host) return DPSX_EINVAL;
+    if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
+    if ((y_n != 1 && y_n != n) || n == 0 || x_next == sample) return DPSX_EINVAL;
+    // S1 (no x0_hat store) -> scoring launch -> one launch for costs + select (+ the winner's replication).
+    // Measured and dropped: S1 fused into the separable scoring kernel (the proposal's halo needs all four input
+    // streams: 72 us for the fused launch against 37 + 30 for the two, N = 64).
+    rc = posterior_fwd(x_t, model_out, noise, nullptr, sample, nullptr, n, c * h * w, to_coefs(coefs_host),
+                       (hipStream_t)stream);
+    if (rc != DPSX_OK) return rc;
+    return score_impl(op, sample, y, y_n, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, c, h, w,
+                      workspace, workspace_bytes, stream, x_next);
 }
 
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,

@@ -529,8 +529,19 @@ __device__ __forceinline__ void vpass_regs(const float *s, float (&acc)[4][4], c
     }
 }
 
+// Waves per SIMD the register allocator may assume: the LDS image of a bucket admits 4 workgroups per CU up to a reach of
+// 12 px (35 KB), 3 at 16-20 px (43-47 KB), 2 beyond (57-74 KB) -- so the wider buckets get 170 / 256 registers instead of
+// spilling at 128 (round 1: up to 482 spilled VGPRs and 1.4 KB of scratch per lane for reach > 12).
+// The plain forward (operator.forward, off the step's hot path) and the two widest adjoint buckets still spilled at
+// those budgets (the 2 x 65 taps no longer fit the SGPR file and move into VGPRs): they trade occupancy for registers.
+constexpr int sep_waves_per_simd(int r4, bool light = false)
+{
+    return light ? (r4 <= 3 ? 4 : (r4 <= 7 ? 2 : 1)) : (r4 <= 3 ? 4 : (r4 <= 5 ? 3 : 2));
+}
+constexpr int sep_adj_waves_per_simd(int r4) { return r4 <= 6 ? sep_waves_per_simd(r4) : 1; }
+
 template <int R4, bool POST, bool RESID>
-__global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
+__global__ __launch_bounds__(NT, sep_waves_per_simd(R4, !POST && !RESID)) void k_blur_sep_fwd(BlurArgs a, SepTaps taps)
 {
     constexpr int RR = 4 * R4;
     using G = SepGeom<RR>;
@@ -543,9 +554,9 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
     if (regular) load_region_reg<RR, POST, true>(s, h0, w0, a, plane);
     else if (!ABL(4)) load_region_fast<RR, POST, true>(s, h0, w0, a, plane);
     else for (int i = threadIdx.x; i < G::RH * G::SW; i += NT) s[i] = (float)i;
-    __syncthreads();
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ox = w0 + 4 * cg;
+    __syncthreads();
     if (!ABL(1)) hpass_inplace<RR>(s, taps.h);
     __syncthreads();
     float acc[4][4];
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_sep_fwd(BlurArgs a, SepTaps taps
 // (tiny or ragged images) take the generic slow folds.
 
 template <int R4, bool EPI>
-__global__ __launch_bounds__(NT, 4) void k_blur_sep_adj(BlurArgs a, SepTaps taps, int reach)
+__global__ __launch_bounds__(NT, sep_adj_waves_per_simd(R4)) void k_blur_sep_adj(BlurArgs a, SepTaps taps, int reach)
 {
     constexpr int RR = 4 * R4;
     using G = SepGeom<RR>;

@@ -1,6 +1,7 @@
 // dpsx internal helpers (gfx950 only: wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <initializer_list>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -414,6 +415,7 @@ int blur_step_bwd(const dpsx_op *op, const StepBwdArgs &a, float *scratch, int64
 int blur_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n, float *partials,
                int64_t n, int64_t c, int64_t h, int64_t w, int l1, const Tail &tail, hipStream_t s);
 int64_t blur_parts_per_particle(const dpsx_op *op, int64_t c, int64_t h, int64_t w);
+
 
 // resize.hip
 int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float *w_w, const int64_t *i_w);

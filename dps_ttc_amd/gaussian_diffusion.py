@@ -457,13 +457,14 @@ class SearchDDPM(DDPM):
             model_out = self._call_model(model, img, idx)
         if noise is None:
             noise = self._randn(img)
-        _, sample = kernels.posterior_fwd(img, model_out, noise, self.step_coefs[idx], want_x0=False)
-        if self.global_select is not None:
-            costs = handle.score(sample, measurement)
-            return self.global_select(costs, sample), costs
-        costs, best, _ = handle.score_argmin(sample, measurement)      # norms + select: one small follow-up launch
+        # S1 -> scoring launch -> costs + select -> the winner's replication: one library call, nothing leaves the device
+        local = self.global_select is None
+        x_next, sample, costs, best, _ = handle.search_step(img, model_out, noise, measurement, self.step_coefs[idx],
+                                                            replicate=local)
         self.last_best = best
-        return kernels.replicate(sample, best), costs
+        if not local:
+            return self.global_select(costs, sample), costs
+        return x_next, costs
 
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, operator,
                       potential_type='min', resample_every_steps=10, rs_temp=0.1, **kwargs):

@@ -204,6 +204,28 @@ class OpHandle:
                                           n, c, h, w, ptr(ws), ws.numel(), stream_of(x)), "dpsx_score_argmin_f32")
         return costs, best, val
 
+    def search_step(self, x_t, model_out, noise, y, coefs, replicate=True):
+        """One search_ddpm step (gaussian_diffusion.py:618-633): S1, costs of the proposals, select and -- with
+        replicate=True -- the winner copied over all particles.  -> (x_next or None, sample, costs, best, costs[best]);
+        one library call, nothing leaves the device."""
+        x_t, model_out, y = _nchw(f32c(x_t, "x_t")), f32c(model_out, "model_out"), f32c(y, "measurement")
+        noise = None if noise is None else f32c(noise, "noise")
+        n, c, h, w = x_t.shape
+        if n == 0:
+            raise ValueError("best-of-N over an empty particle set")
+        if model_out.shape[0] != n or model_out[0].numel() != 2 * c * h * w:
+            raise ValueError(f"model_out {tuple(model_out.shape)} does not hold 2x the channels of x {tuple(x_t.shape)}")
+        sample = torch.empty_like(x_t)
+        x_next = torch.empty_like(x_t) if replicate else None
+        costs = torch.empty(n, dtype=torch.float32, device=x_t.device)
+        best = torch.empty((), dtype=torch.int64, device=x_t.device)
+        val = torch.empty(1, dtype=torch.float32, device=x_t.device)
+        ws = self.workspace(n, c, h, w, x_t.device)
+        check(lib().dpsx_search_step_f32(self._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0], ptr(sample),
+                                         ptr(costs), ptr(best), ptr(val), ptr(x_next), n, c, h, w, byref(coefs), ptr(ws),
+                                         ws.numel(), stream_of(x_t)), "dpsx_search_step_f32")
+        return x_next, sample, costs, best, val
+
     def resample_cost(self, x, y, prev_costs=None, potential_type='min'):
         """SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585) in one launch:
         curr[p] = ||y - A(x_p)||_1^2 / (C H W), net = combine(curr, prev_costs) -> (curr, net)."""

@@ -195,6 +195,17 @@ int dpsx_score_argmin_f32(dpsx_op *op, const float *x, const float *y, int64_t y
                           int64_t n, int64_t c, int64_t h, int64_t w,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* One step of SearchDDPM.p_sample_loop (gaussian_diffusion.py:618-633): S1 (p_sample: `sample` out; x0_hat is not
+ * needed by this loop), costs[p] = ||y - A(sample_p)||_2, best = argmin (torch.argmin order) and, if x_next != NULL,
+ * x_next[p] = sample[best] for every p (img[best_path.repeat(n_paths)]).  Four launches: S1, the scoring launch, one
+ * small launch that finishes the costs and selects, the replication.  x_next == NULL: up to the select only (multi-GPU callers
+ * exchange the champions first). */
+int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise,
+                         const float *y, int64_t y_n, float *sample, float *costs,
+                         int64_t *best_idx_dev, float *best_val_dev, float *x_next,
+                         int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
 /* SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585):
  *   curr[p] = ||y - A(x_p)||_1^2 / (c*h*w)                                         (:557-563)
  *   net[p]  = curr + prev (MEAN) | min(curr, prev) (MIN, NaN propagates as torch.min) | curr - prev (DIFF) | curr (CURR)

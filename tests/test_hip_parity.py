@@ -945,3 +945,31 @@ def test_taps_regular_multi_tile(K, oracle, kind, seed, hw):
     lhs = (y.double() * dev(u).double()).sum().item()
     rhs = (dev(x).double() * g.double()).sum().item()
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), np.sqrt(float(y.numel())))
+
+
+@pytest.mark.parametrize("name,hw,n", [("gauss", 256, 9), ("gauss", 64, 5), ("gauss", 128, 3), ("gauss", 46, 4), ("sr4", 256, 5),
+                                       ("inpaint", 64, 4), ("motion", 128, 3), ("phase", 32, 2)])
+@pytest.mark.parametrize("t", [700, 0])
+def test_search_step_fused_equals_separate(K, oracle, name, hw, n, t):
+    """dpsx_search_step_f32 (S1, scoring launch, one launch for costs + select + replication) ==
+    dpsx_posterior_fwd_f32 + dpsx_score_argmin_f32 + dpsx_replicate_f32, bit for bit: sample, costs, winner, x_next"""
+    rng = np.random.RandomState(hw + n + t)
+    mask = (np.random.RandomState(3).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5), mask=mask)
+    _, ck = coefs_of(K, oracle, t)
+    x = dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    mo = dev(rng.randn(n, 6, hw, hw).astype(np.float32) * 0.5)
+    z = dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(x)
+    y = op.forward(dev(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32)), **fkw).detach().contiguous()
+    for yy in (y, y.expand(n, *y.shape[1:]).contiguous()):
+        _, ref_sample = K.posterior_fwd(x, mo, z, ck, want_x0=False)
+        ref_costs, ref_best, ref_val = handle.score_argmin(ref_sample, yy)
+        for replicate in (True, False):
+            x_next, sample, costs, best, val = handle.search_step(x, mo, z, yy, ck, replicate=replicate)
+            assert torch.equal(sample, ref_sample) and torch.equal(costs, ref_costs)
+            assert int(best) == int(ref_best) == int(torch.argmin(ref_costs)) and torch.equal(val, ref_val)
+            if replicate:
+                assert torch.equal(x_next, ref_sample[int(ref_best)].unsqueeze(0).expand_as(x_next))
+            else:
+                assert x_next is None

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--unfused", action="store_true", help="separate score / argmin launches (the round-1 sequence)")
+    ap.add_argument("--unfused", action="store_true", help="S1 and the scoring launch separately (the sequence other operators run)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -37,12 +37,13 @@ def main():
 
     def step(i, x):
         s = ring[i % 2]
+        if not args.unfused:        # what SearchDDPM.search_step runs: dpsx_search_step_f32 + dpsx_replicate_f32
+            return handle.search_step(x, s["model_out"], s["noise"], y, ck)[0]
         _, sample = kernels.posterior_fwd(x, s["model_out"], s["noise"], ck, want_x0=False)
         if args.unfused:
-            costs = handle.score(sample, y)
-            return kernels.replicate(sample, kernels.argmin(costs))
-        costs, best, _ = handle.score_argmin(sample, y)
-        return kernels.replicate(sample, best)
+            costs, best, _ = handle.score_argmin(sample, y)
+            return kernels.replicate(sample, best)
+        return None
 
     x = x_t
     for i in range(3):
@@ -55,6 +56,25 @@ def main():
         b.record()
     torch.cuda.synchronize()
     ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    # the launches one by one (each timed alone, back to back with itself)
+    s0 = ring[0]
+    _, sample = kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck, want_x0=False)
+    costs, best, _ = handle.score_argmin(sample, y)
+    parts = {"search_step w/o replicate": lambda: handle.search_step(x, s0["model_out"], s0["noise"], y, ck, replicate=False),
+             "S1 (no x0_hat store)": lambda: kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck, want_x0=False),
+             "score + finalize/select": lambda: handle.score_argmin(sample, y),
+             "replicate": lambda: kernels.replicate(sample, best)}
+    for name, fn in parts.items():
+        for _ in range(3):
+            fn()
+        e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
+        for a_, b_ in e:
+            a_.record()
+            fn()
+            b_.record()
+        torch.cuda.synchronize()
+        tt = np.array([a_.elapsed_time(b_) for a_, b_ in e]) * 1e3
+        print(f"    {name:28s} avg {tt.mean():6.1f} us  min {tt.min():6.1f} us")
     algo = 8 * bench.P_BYTES * n
     print(f"search step N={n} {args.operator}: avg {ts.mean():.1f} us  min {ts.min():.1f} us  "
           f"{n / ts.mean() * 1e6:.0f} particle-steps/s  {algo / ts.mean() / 1e3:.0f} GB/s algorithmic (8P/particle)")

@@ -146,12 +146,13 @@ def synth_inputs(n, ring, device, seed):
     return x_t.to(device), sets, truth, meas_noise
 
 
-def build_operator(name, device):
+def build_operator(name, device, sigma=3.0):
+    """sigma: only tools/kbench.py passes another value (other radius buckets); the bench itself runs sigma = 3.0"""
     import numpy as np
     import torch
     from dps_ttc_amd.measurements import get_operator
     if name == "gaussian_blur":
-        return get_operator("gaussian_blur", kernel_size=61, intensity=3.0, device=device), {}
+        return get_operator("gaussian_blur", kernel_size=61, intensity=sigma, device=device), {}
     if name == "motion_blur":
         np.random.seed(0)
         return get_operator("motion_blur", kernel_size=61, intensity=0.5, device=device), {}

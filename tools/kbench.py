@@ -23,13 +23,14 @@ def main():
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="fwd,bwd,upd,op,adj,score")
+    ap.add_argument("--sigma", type=float, default=3.0, help="gaussian_blur only: another radius bucket")
     ap.add_argument("--norm-in-fwd", action="store_true", help="K1 finishes the norm itself (last block of a particle)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
     dev = torch.device("cuda", 0)
     n = args.particles
-    op, fkw = bench.build_operator(args.operator, dev)
+    op, fkw = bench.build_operator(args.operator, dev, sigma=args.sigma)
     smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
                          model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
                          rescale_timesteps=True, timestep_respacing="")

@@ -16,7 +16,7 @@ import glob
 import json
 import sys
 
-ROLE = [("k_blur_sep_fwd", "fwd"), ("k_blur_taps_fwd", "fwd"), ("k_resize_fwd", "fwd"), ("k_mask_step_fwd", "fwd"),
+ROLE = [("k_blur_sep_fwd", "fwd"), ("k_blur_taps<true, 1", "fwd"), ("k_resize_fwd", "fwd"), ("k_mask_step_fwd", "fwd"),
         ("k_blur_sep_adj", "bwd"), ("k_blur_taps_adj", "bwd"), ("k_resize_adj", "bwd"), ("k_mask_step_bwd", "bwd"),
         ("k_step_update", "upd"), ("k_finalize_norm", "finalize")]
 

@@ -555,10 +555,35 @@ __global__ __launch_bounds__(kThreads) void k_gather_scalar(const float *__restr
     dst[p * chw + i] = (sidx < 0 || sidx >= n_src) ? __builtin_nanf("") : src[sidx * chw + i];
 }
 
+// dst[p] = src[*idx] for all p: a lane reads its float4 of the winner once and stores it to kRepl destinations
+// (one block per (slice, group of kRepl particles): 8x fewer, fatter blocks than one per destination particle)
+constexpr int kRepl = 8;
+__global__ __launch_bounds__(kThreads) void k_replicate(const float *__restrict__ src, const int64_t *__restrict__ idx,
+                                                        float *__restrict__ dst, int64_t n_out, int64_t n_src,
+                                                        int64_t chw4)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= chw4) return;
+    const int64_t sidx = idx[0];
+    const float q = __builtin_nanf("");
+    const float4 v = (sidx < 0 || sidx >= n_src) ? make_float4(q, q, q, q)
+                                                 : (reinterpret_cast<const float4 *>(src) + sidx * chw4)[i];
+    const int64_t p0 = (int64_t)blockIdx.y * kRepl;
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + p0 * chw4 + i;
+#pragma unroll
+    for (int k = 0; k < kRepl; ++k)
+        if (p0 + k < n_out) d4[(int64_t)k * chw4] = v;
+}
+
 int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
                bool replicate, hipStream_t s)
 {
     if (n_out == 0 || chw == 0) return DPSX_OK;
+    if (replicate && chw % 4 == 0 && aligned16(src) && aligned16(dst)) {
+        const dim3 grid((unsigned)((chw / 4 + kThreads - 1) / kThreads), (unsigned)((n_out + kRepl - 1) / kRepl));
+        k_replicate<<<grid, kThreads, 0, s>>>(src, ids, dst, n_out, n_src, chw / 4);
+        return check_launch();
+    }
     if (chw % 4 == 0 && aligned16(src) && aligned16(dst))
         k_gather<<<grid_for(chw / 4, n_out), kThreads, 0, s>>>(src, ids, dst, n_src, chw / 4, replicate);
     else

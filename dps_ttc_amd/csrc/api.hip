@@ -191,6 +191,15 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
                 i = dy0 + L + R;                                       // first row not covered by this run
             }
         }
+        // an even number of runs per class (the pipelined loop works on pairs): a dummy run repeats the last offsets
+        // with zero weights
+        for (int c = 0; c < 4; ++c)
+            if (cls_f[c].size() % 2) {
+                TapRun f = cls_f[c].back(), t = cls_a[c].back();
+                for (int q = 0; q < 4; ++q) f.w[q] = t.w[q] = 0.0f;
+                cls_f[c].push_back(f);
+                cls_a[c].push_back(t);
+            }
         std::vector<TapRun> fwd, adj;
         for (int c = 0; c < 4; ++c) {
             op->nrun[c] = (int)cls_f[c].size();

@@ -23,6 +23,7 @@
 namespace dpsx {
 
 constexpr int TH = 64, TW = 64, NT = 256;
+constexpr size_t kScratchBytes = 1024;     // reduction scratch behind every kernel's LDS image
 
 struct BlurArgs {
     // plain input / output
@@ -434,6 +435,10 @@ struct RunClip {          // zero-extended sources (adjoint): the source plane's
 // index turns into scalar loads (s_load_dwordx8 into SGPRs; weights then feed v_pk_fma_f32 as scalar operands).  Through
 // the generic pointer the compiler must assume the kernel's own stores may alias the table and falls back to vector
 // loads plus per-lane selects -- 2.5x the VALU instructions of the FMAs themselves (measured: SQ_INSTS_VALU).
+// Measured and dropped in round 2 (plain forward, N = 64, 50.5 us with this loop): two runs per iteration behind one
+// wait (52.4), the table in LDS with a software-pipelined loop (next window's reads issued before this run's FMAs: 57.2),
+// the table in VGPRs broadcast with v_readlane_b32 (61-83: the selects end up in VGPRs).  An ablation build shows the
+// record fetches themselves cost 1.4 us; what the loop is short of is waves per SIMD (LDS admits four workgroups per CU).
 typedef const __attribute__((address_space(4))) TapRun *ConstRuns;
 __device__ __forceinline__ TapRun load_run(const TapRun *runs, int i)
 {
@@ -454,38 +459,81 @@ __device__ __forceinline__ bool run_live(const TapRun &r, const RunClip &clip)
            r.dx < clip.col_hi;
 }
 
-// One run on the lane's window.  Even dx: (PRW + L - 1) 8-byte reads, PRW * L packed FMAs.  Odd dx: the pair of columns
-// (2cp + dx, 2cp + dx + 1) straddles two aligned 8-byte words, so the lane reads both -- (x0, x1) at 2cp + dx - 1 and
-// (x2, x3) at 2cp + dx + 1 -- and uses x1 for its left column, x2 for its right one: 2 (PRW + L - 1) reads and
-// 2 PRW L scalar FMAs (the same FMA-pipe time as the packed form; `ds_read2_b32` on the odd address would cost the same
-// LDS cycles on paper but runs into 2-way bank conflicts: 32 lanes x stride-2 dwords on 32 banks -- measured, 33 % of all
-// LDS cycles).  The reads are volatile so that the backend does not fuse two of them into one `ds_read2_b64`, which
-// moves 128 B per LDS clock where two `ds_read_b64` move 256.
+// One run on the lane's window: (PRW + L - 1) 8-byte reads, PRW * L packed FMAs -- for BOTH parities of dx.  An 8-byte
+// LDS read must be 8-byte aligned, so a lane cannot fetch the inputs (2cp + dx, 2cp + dx + 1) of its column pair when dx
+// is odd.  Round 2's first form read the two aligned words that straddle the pair and used scalar `v_fma_f32` on the inner
+// halves: twice the reads and -- the SQ counters showed it (SQ_INSTS_VALU = 2.0x the packed-FMA count of the tap list,
+// VALU busy 60 % of the launch) -- twice the FMA-pipe time, a wave-wide v_fma_f32 costs the same four cycles as a
+// v_pk_fma_f32.  Now odd-dx runs accumulate the SHIFTED output pair (2cp - 1, 2cp), whose inputs (2cp - 1 + dx, 2cp + dx)
+// are aligned, into a second accumulator set `aco`; the two sets are merged once per tile (merge_shifted: the lane's own
+// .y plus its right neighbour's .x, one lane shift).  The shifted pairs cover columns -1 .. 62, so column 63's odd-dx part
+// is accumulated separately: lane l of a wave keeps `c63` for the wave's row (l & 15), L dword reads + L FMAs per run.
+// The reads are volatile so that the backend does not fuse two of them into one `ds_read2_b64`, which moves 128 B per LDS
+// clock where two `ds_read_b64` move 256.
 typedef const volatile __attribute__((address_space(3))) v2f *LdsPair;     // explicit LDS pointer: volatile must not demote the read to a flat load
 
-template <int L, bool ODD, int SWC>
-__device__ __forceinline__ void run_apply(v2f (&acc)[PRW], const float *base, const int SW, const TapRun &r)
+// p: the lane's window base for this run (lowest row; the even column the 8-byte reads start at).
+// REV: the lane's rows are visited in descending order (mirrored rows of the one-launch adjoint): acc[PRW-1-i] pairs with
+// window row i + q.  SWAP: the pair is mirrored horizontally (low input column feeds the high output column).
+template <int L, int SWC, bool REV, bool SWAP, int PR = PRW>
+__device__ __forceinline__ void run_apply(v2f (&acc)[PR], const float *p, const int SW, const TapRun &r)
 {
-    const float *p = base + r.dy0 * SW + r.dx - (ODD ? 1 : 0);
-    v2f wa[PRW + L - 1], wb[ODD ? PRW + L - 1 : 1];
+    v2f wa[PR + L - 1];
 #pragma unroll
-    for (int m = 0; m < PRW + L - 1; ++m) {
-        wa[m] = *(LdsPair)(p + m * SW);
-        if constexpr (ODD) wb[m] = *(LdsPair)(p + m * SW + 2);
-    }
+    for (int m = 0; m < PR + L - 1; ++m) wa[m] = *(LdsPair)(p + m * SW);
 #pragma unroll
     for (int q = 0; q < L; ++q) {
-        if constexpr (ODD) {
+        const v2f w2 = v2f{r.w[q], r.w[q]};
 #pragma unroll
-            for (int i = 0; i < PRW; ++i) {
-                acc[i].x = fmaf(r.w[q], wa[i + q].y, acc[i].x);
-                acc[i].y = fmaf(r.w[q], wb[i + q].x, acc[i].y);
-            }
-        } else {
-            const v2f w2 = v2f{r.w[q], r.w[q]};
-#pragma unroll
-            for (int i = 0; i < PRW; ++i) acc[i] = __builtin_elementwise_fma(w2, wa[i + q], acc[i]);   // v_pk_fma_f32
+        for (int i = 0; i < PR; ++i) {
+            const v2f in = SWAP ? v2f{wa[i + q].y, wa[i + q].x} : wa[i + q];      // op_sel of v_pk_fma_f32, no move
+            v2f &dst = acc[REV ? PR - 1 - i : i];
+            dst = __builtin_elementwise_fma(w2, in, dst);                           // v_pk_fma_f32
         }
+    }
+}
+
+// the column the shifted pairs leave out (63): one row per lane, 16 rows per wave.  All 16 lanes read the SAME column, so
+// with a row stride that is a multiple of 32 words every read would be a 16-way bank conflict (measured: the plain
+// forward went from 58 to 72 us); the compile-time strides are 100 / 132 words and the read is the aligned 8-byte pair
+// (63 + dx is even): 16 rows x 100 words land on 16 distinct bank pairs of the 64-bank b64 map.
+template <int L>
+__device__ __forceinline__ void run_apply_col(float &c, const float *p, const int SW, const TapRun &r)
+{
+    float in[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) in[q] = (*(LdsPair)(p + q * SW)).x;
+#pragma unroll
+    for (int q = 0; q < L; ++q) c = fmaf(r.w[q], in[q], c);
+}
+
+// per-lane accumulators of one pass over the tap table
+template <int PR>
+struct TapAccT {
+    v2f ac[PR];       // columns (2cp, 2cp + 1), rows r0 .. r0 + PR - 1
+    v2f aco[PR];      // columns (2cp - 1, 2cp): the runs whose inputs for (2cp, 2cp + 1) would be unaligned
+    float c63;        // the left-out column of `aco`, row (lane & 15) of the wave
+};
+typedef TapAccT<PRW> TapAcc;
+
+template <int PR>
+__device__ __forceinline__ void tapacc_zero(TapAccT<PR> &t)
+{
+#pragma unroll
+    for (int i = 0; i < PR; ++i) t.ac[i] = t.aco[i] = v2f{0.0f, 0.0f};
+    t.c63 = 0.0f;
+}
+
+// ac += the shifted set: out[2cp] += aco.y, out[2cp + 1] += aco.x of the lane to the right (column 63: c63 of the row)
+__device__ __forceinline__ void merge_shifted(TapAcc &t)
+{
+    const int lane = threadIdx.x & 63, cp = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < PRW; ++i) {
+        const float nb = __shfl_down(t.aco[i].x, 1, kWave);
+        const float cc = __shfl(t.c63, half * PRW + i, kWave);
+        t.ac[i].x += t.aco[i].y;
+        t.ac[i].y += cp == 31 ? cc : nb;
     }
 }
 
@@ -493,35 +541,49 @@ __device__ __forceinline__ void run_apply(v2f (&acc)[PRW], const float *base, co
 // per CU), not by pipelining inside a wave: a hand-pipelined form (next run's window loaded before this run's FMAs, two
 // register sets) cost 44 register moves per pair of runs and was slower.  The next record's scalar loads are issued a
 // run ahead.
+// The runs of one class.  Latency is hidden by the four or more waves that share a SIMD (one workgroup per tile, four
+// per CU), not by pipelining inside a wave (see load_run).  The next record's scalar loads are issued a run ahead.
 template <int L, bool ODD, int SWC, bool CLIP>
-__device__ __forceinline__ void tap_runs_pk(v2f (&acc)[PRW], const float *base, const int sw_rt, const TapRun *runs,
-                                            const int nruns, const RunClip clip)
+__device__ __forceinline__ void tap_runs_pk(TapAcc &t, const float *base, const float *base63, const int sw_rt,
+                                            const TapRun *runs, const int nruns, const RunClip clip)
 {
     const int SW = SWC > 0 ? SWC : sw_rt;
     if (nruns <= 0) return;
     TapRun r = load_run(runs, 0);
-    for (int t = 0; t < nruns; ++t) {
-        const TapRun nxt = load_run(runs, min(t + 1, nruns - 1));
-        if (run_live<CLIP, L>(r, clip)) run_apply<L, ODD, SWC>(acc, base, SW, r);
+    for (int k = 0; k < nruns; ++k) {
+        const TapRun nxt = load_run(runs, min(k + 1, nruns - 1));
+        if (run_live<CLIP, L>(r, clip)) {
+            const int o = r.dy0 * SW + r.dx;
+            if constexpr (ODD) {
+                run_apply<L, SWC, false, false>(t.aco, base + o - 1, SW, r);
+                run_apply_col<L>(t.c63, base63 + o, SW, r);
+            } else {
+                run_apply<L, SWC, false, false>(t.ac, base + o, SW, r);
+            }
+        }
         r = nxt;
     }
 }
 
-// all runs of a table on the staged image s_in (row stride SW, even): acc[i] = columns (2cp, 2cp+1) of row r0 + i
+// all runs of a table on the staged image s_in (row stride SW, even): acc[i] = columns (2cp, 2cp+1) of row r0 + i.
+// org: LDS word of (row r0, column 2cp) of the tile; org63: of (the wave's row lane & 15, column 63)
 template <int SWC, bool CLIP>
 __device__ __forceinline__ void tap_all_runs(v2f (&acc)[PRW], const float *s_in, const int SW, const int org,
-                                             const BlurArgs &a, const RunClip clip)
+                                             const int org63, const BlurArgs &a, const RunClip clip)
 {
-#pragma unroll
-    for (int i = 0; i < PRW; ++i) acc[i] = v2f{0.0f, 0.0f};
+    TapAcc t;
+    tapacc_zero(t);
     const TapRun *r = a.runs;
-    tap_runs_pk<4, false, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[0], clip);
+    tap_runs_pk<4, false, SWC, CLIP>(t, s_in + org, s_in + org63, SW, r, a.nrun[0], clip);
     r += a.nrun[0];
-    tap_runs_pk<2, false, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[1], clip);
+    tap_runs_pk<2, false, SWC, CLIP>(t, s_in + org, s_in + org63, SW, r, a.nrun[1], clip);
     r += a.nrun[1];
-    tap_runs_pk<4, true, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[2], clip);
+    tap_runs_pk<4, true, SWC, CLIP>(t, s_in + org, s_in + org63, SW, r, a.nrun[2], clip);
     r += a.nrun[2];
-    tap_runs_pk<2, true, SWC, CLIP>(acc, s_in + org, SW, r, a.nrun[3], clip);
+    tap_runs_pk<2, true, SWC, CLIP>(t, s_in + org, s_in + org63, SW, r, a.nrun[3], clip);
+    if (a.nrun[2] + a.nrun[3] > 0) merge_shifted(t);          // launch-uniform
+#pragma unroll
+    for (int i = 0; i < PRW; ++i) acc[i] = t.ac[i];
 }
 
 // ---------------------------------------------------------------- kernels
@@ -560,7 +622,12 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
         clip = RunClip{a.src_off - wr0, a.src_off + a.src_h - wr0, a.src_off - w0, a.src_off + a.src_w - w0};
     }
     v2f acc[PRW];
-    tap_all_runs<SWC, !REFLECT>(acc, s_in, SW, (r0 + g.t) * SW + 2 * cp + g.l, a, clip);
+    const int row63 = (tid >> 6) * 2 * PRW + (tid & 15);       // the shifted pairs' left-out column: one row per lane
+    if (ABL(16)) {      // ablation: no tap loop at all (what the load / store phases of the launch cost by themselves)
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) acc[i] = *(LdsPair)(s_in + (r0 + g.t + i) * SW + 2 * cp + g.l);
+    } else
+    tap_all_runs<SWC, !REFLECT>(acc, s_in, SW, (r0 + g.t) * SW + 2 * cp + g.l, (row63 + g.t) * SW + 63 + g.l, a, clip);
     const int ox = w0 + 2 * cp;
     const bool full = VEC && a.h % TH == 0 && a.w % TW == 0;
     float ss = 0.0f;
@@ -602,6 +669,242 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
         const float t = block_sum(ss, s_red);
         if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t);
         tail_arrive(a.tail, plane / a.c);
+    }
+}
+
+// =====================================================================
+// One-launch adjoint for regular geometry (h, w multiples of the tile): A^T u on the IMAGE domain, no padded-domain
+// scratch, no fold launch.  With V = C^T u_z the correlation-transpose of the zero-extended cotangent,
+//     (A^T u)[jy][jx] = sum over my in M(jy), mx in M(jx) of V[my][mx],   M(j) = {j} + {-j : j >= 1} + {2(n-1)-j : j <= n-2}
+// (the reflection fold; V vanishes beyond the taps' reach, so the far mirror terms drop out by themselves).  A mirrored
+// term is the SAME tap loop on a mirrored window of the staged tile: V[-jy][.] = sum_d w'[d] u_z[-jy + dy][.] reads the
+// rows of u in DESCENDING order as jy ascends, so a lane applies each run to the window starting at row
+// (c - r0 - 7 + dy0) with its eight accumulators visited backwards (c = 0 for the top border, 2 * 63 for the bottom one,
+// in tile coordinates); mirrored columns likewise swap the two halves of every 8-byte pair (op_sel of v_pk_fma_f32) and
+// exchange the roles of the plain and the shifted accumulator sets (the parity of c - column + dx flips).  Windows that
+// slide off the staged region are clamped onto its zero rows / columns: the staged halo is at least 11 rows / 4 columns,
+// so a clamped window lies wholly in the zero extension whenever the true one does.  Per tile up to nine passes
+// {plain, top, bottom} x {plain, left, right}; every pass skips, wave-uniformly, the runs that cannot reach the image from
+// the wave's rows, and whole passes when the wave's rows are out of the taps' reach of the border.  Deterministic, no
+// atomics; round 2's two-launch form (padded-domain V in scratch + fold kernel: 111 + 18 us at N = 64) stays as the
+// fallback for ragged sizes.  A previous one-launch attempt computed V on the tile PLUS its reflection ring and folded
+// through LDS (140-173 us): the ring patches landed on one or two of the four waves and the LDS image grew by the ring.
+// =====================================================================
+struct AdjReach { int t, b, l, r; };     // the adjoint taps reach dy in [-t, b], dx in [-l, r]
+
+struct AdjLane {
+    int rb, cb, cbo, rb63;               // window bases before the run's offsets: rows, plain / shifted column pair, c63 row
+    int row_lo, row_hi, col_lo, col_hi;  // clamps of the window base (tile coordinates)
+    int dyl, dyh, dxl, dxh;              // wave-uniform liveness of a run: dy0 + L - 1 >= dyl, dy0 <= dyh, dxl <= dx <= dxh
+};
+
+template <int L, bool ODD, int SWC, bool RY, bool RX, int PR>
+__device__ __forceinline__ void adj_runs(TapAccT<PR> &t, const float *s0, const int sw_rt, const AdjLane &ln,
+                                         const TapRun *runs, const int nruns)
+{
+    const int SW = SWC > 0 ? SWC : sw_rt;
+    if (nruns <= 0) return;
+    constexpr bool SHIFTED = RX ? !ODD : ODD;        // which accumulator set has aligned inputs for this dx parity
+    TapRun r = load_run(runs, 0);
+    for (int k = 0; k < nruns; ++k) {
+        const TapRun nxt = load_run(runs, min(k + 1, nruns - 1));
+        if (r.dy0 + L - 1 >= ln.dyl && r.dy0 <= ln.dyh && r.dx >= ln.dxl && r.dx <= ln.dxh) {
+            int row = ln.rb + r.dy0, col = (SHIFTED ? ln.cbo : ln.cb) + r.dx;
+            if constexpr (RY) row = min(max(row, ln.row_lo), ln.row_hi - (PR + L - 1));
+            if constexpr (RX) col = min(max(col, ln.col_lo), ln.col_hi - 2);
+            run_apply<L, SWC, RY, RX, PR>(SHIFTED ? t.aco : t.ac, s0 + row * SW + col, SW, r);
+            if constexpr (SHIFTED && !RX) {          // (mirrored-column passes never owe column 63 anything: see the caller)
+                int r63 = ln.rb63 + r.dy0;
+                if constexpr (RY) r63 = min(max(r63, ln.row_lo), ln.row_hi - L);
+                run_apply_col<L>(t.c63, s0 + r63 * SW + 63 + r.dx, SW, r);
+            }
+        }
+        r = nxt;
+    }
+}
+
+template <int SWC, bool RY, bool RX, int PR>
+__device__ __forceinline__ void adj_all_runs(TapAccT<PR> &t, const float *s0, const int SW, const AdjLane &ln, const BlurArgs &a)
+{
+    tapacc_zero(t);
+    const TapRun *r = a.runs;
+    adj_runs<4, false, SWC, RY, RX, PR>(t, s0, SW, ln, r, a.nrun[0]);
+    r += a.nrun[0];
+    adj_runs<2, false, SWC, RY, RX, PR>(t, s0, SW, ln, r, a.nrun[1]);
+    r += a.nrun[1];
+    adj_runs<4, true, SWC, RY, RX, PR>(t, s0, SW, ln, r, a.nrun[2]);
+    r += a.nrun[2];
+    adj_runs<2, true, SWC, RY, RX, PR>(t, s0, SW, ln, r, a.nrun[3]);
+}
+
+template <int SWC, bool RY, bool RX>
+__device__ __forceinline__ void adj_pass(TapAcc &t, const float *s0, const int SW, const AdjLane &ln, const BlurArgs &a)
+{
+    adj_all_runs<SWC, RY, RX, PRW>(t, s0, SW, ln, a);
+    merge_shifted(t);
+}
+
+// Mirrored-COLUMN pass on a narrow strip.  Only the columns within the taps' reach of the left / right border receive
+// anything from it (12 of 64 for the bench kernel), but every wave owns all 64 columns of its 16 rows: in the plain lane
+// layout 80 % of the lanes multiplied staged zeros (ablation at N = 64: +26 us for the column mirrors against 62 us for
+// the whole plain pass).  Here the wave's 64 lanes are re-dealt over the strip alone -- W = 8 (16) column pairs x 8 (4)
+// row groups of PR = 2 (4) rows -- so all lanes carry live outputs; the results return to the owner lanes of the plain
+// layout with one `ds_bpermute` per value (same wave, no barrier, no LDS storage).  Row groups of a half-wave are 4 (8)
+// rows apart: with the 100 / 132-word strides their 8-byte reads fall on disjoint bank ranges.
+// The strip is wide enough that its outermost column pair's neighbour contributes nothing (reach <= 2 W - 2).
+template <int SWC, bool RY, int PR>
+__device__ __forceinline__ void adj_strip_pass(v2f (&acc)[PRW], const float *s0, const int SW, AdjLane ln, const BlurArgs &a,
+                                               const int py, const int px, const int cy, const int cx, const int wr0,
+                                               const int r0)
+{
+    constexpr int W = PR == 2 ? 8 : 16, NH = 32 / W;          // column pairs per strip row; row groups per half-wave
+    const int lane = threadIdx.x & 63;
+    const int cps = lane & (W - 1), k = lane / W, half = k / NH, j = k % NH;
+    const int row_s = wr0 + j * (2 * PRW / NH) + half * PR;     // first of the lane's PR rows (tile coordinates)
+    const int cp_base = px == 2 ? 32 - W : 0, cp = cp_base + cps;
+    ln.rb = RY ? cy - row_s - (PR - 1) : row_s;
+    ln.cb = cx - 2 * cp - 1;
+    ln.cbo = cx - 2 * cp;
+    TapAccT<PR> t;
+    adj_all_runs<SWC, RY, true, PR>(t, s0, SW, ln, a);
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        const float nb = __shfl_down(t.aco[i].x, 1, kWave);
+        t.ac[i].x += t.aco[i].y;
+        t.ac[i].y += cps == W - 1 ? 0.0f : nb;
+        // the border pixel itself is its own mirror image
+        const int trow = row_s + i;
+        const bool xr = (py == 1 && trow == 0) || (py == 2 && trow == TH - 1);
+        if (xr || (px == 1 && cp == 0)) t.ac[i].x = 0.0f;
+        if (xr || (px == 2 && cp == 31)) t.ac[i].y = 0.0f;
+    }
+    // back to the plain layout: owner lane (column pair cpo, rows r0 .. r0 + 7) pulls row rho = r0 - wr0 + i of the strip
+    const int rel = (int)(threadIdx.x & 31) - cp_base;
+    const bool mine = rel >= 0 && rel < W;
+#pragma unroll
+    for (int i = 0; i < PRW; ++i) {
+        const int rho = r0 - wr0 + i;
+        const int grp = PR == 2 ? 4 * ((rho >> 1) & 1) + (rho >> 2) : 2 * ((rho >> 2) & 1) + (rho >> 3);
+        const int src = (rel & (W - 1)) + W * grp;
+        const float vx = __shfl(t.ac[i % PR].x, src, kWave), vy = __shfl(t.ac[i % PR].y, src, kWave);
+        acc[i].x += mine ? vx : 0.0f;
+        acc[i].y += mine ? vy : 0.0f;
+    }
+}
+
+template <bool EPI, int SWC>
+__global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, AdjReach reach)
+{
+    const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = SWC > 0 ? SWC : RW;
+    extern __shared__ __align__(16) float lds[];
+    float *s_in = lds, *s_red = lds + RH * SW;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    const int n = plane / a.c, ch = plane % a.c;
+    NormPartials np{};
+    const bool own_norm = EPI && !a.norm_in;
+    if constexpr (EPI) {
+        if (own_norm && threadIdx.x < kWave) np = particle_norm_issue(a.norm_partials, a.norm_parts, n);
+    }
+    load_region_taps_first<false, false, 4>(s_in, SW, RW / 4, g, h0, w0, a, plane);
+    if constexpr (EPI) {
+        if (own_norm) particle_norm_reduce(np, a.norm_parts, s_red);
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    // which 16 rows a wave owns rotates from tile to tile: the mirrored-row passes always fall on the first / last row
+    // block of a border tile, and would otherwise pile up on one SIMD of the CU
+    const int wv = ((tid >> 6) + tx + ty + plane) & 3;
+    const int cp = tid & 31, wr0 = wv * 2 * PRW, r0 = wr0 + ((tid >> 5) & 1) * PRW, l15 = lane & 15;
+    const float *s0 = s_in + g.t * SW + g.l;          // tile coordinates (0, 0)
+    const bool top = ty == 0, bot = ty == a.tiles_y - 1, lef = tx == 0, rig = tx == a.tiles_x - 1;
+    constexpr int BIG = 1 << 20, CM = 2 * (TH - 1);   // mirror constant of the far border in tile coordinates
+    v2f acc[PRW];
+    TapAcc t;
+    AdjLane ln;
+    ln.row_lo = -g.t; ln.row_hi = TH + g.b; ln.col_lo = -g.l; ln.col_hi = TW + g.r;
+#pragma unroll 1
+    for (int py = 0; py < 3; ++py) {
+        // rows: plain | mirrored about the top border (image row 0) | about the bottom border (image row h - 1)
+        if (py && ABL(1)) continue;
+        if (py == 1 && !(top && max(wr0, 1) <= reach.b)) continue;               // wave-uniform
+        if (py == 2 && !(bot && min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1) >= -reach.t)) continue;
+        const int cy = py == 2 ? CM : 0;
+        ln.rb = py ? cy - r0 - (PRW - 1) : r0;
+        ln.rb63 = py ? cy - (wr0 + l15) : wr0 + l15;
+        ln.dyl = py == 0 ? -h0 - wr0 - (2 * PRW - 1) : (py == 1 ? max(wr0, 1) : -BIG);
+        ln.dyh = py == 0 ? a.h - 1 - h0 - wr0 : (py == 1 ? BIG : min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1));
+#pragma unroll 1
+        for (int px = 0; px < 3; ++px) {
+            if (px && ABL(2)) continue;
+            if (px == 1 && !(lef && reach.r >= 1)) continue;                       // launch / block uniform
+            if (px == 2 && !(rig && reach.l >= 1)) continue;
+            const int cx = px == 2 ? CM : 0;
+            ln.cb = px ? cx - 2 * cp - 1 : 2 * cp;
+            ln.cbo = px ? cx - 2 * cp : 2 * cp - 1;
+            ln.dxl = px == 0 ? -w0 - (TW - 1) : (px == 1 ? 1 : -BIG);
+            ln.dxh = px == 0 ? a.w - 1 - w0 : (px == 1 ? BIG : -1);
+            if (px) {
+                const int rch = px == 1 ? reach.r : reach.l;
+                if (rch <= 14) {
+                    if (py == 0) adj_strip_pass<SWC, false, 2>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
+                    else adj_strip_pass<SWC, true, 2>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
+                    continue;
+                }
+                if (rch <= 30) {
+                    if (py == 0) adj_strip_pass<SWC, false, 4>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
+                    else adj_strip_pass<SWC, true, 4>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
+                    continue;
+                }
+            }
+            if (py == 0 && px == 0) adj_pass<SWC, false, false>(t, s0, SW, ln, a);
+            else if (px == 0) adj_pass<SWC, true, false>(t, s0, SW, ln, a);
+            else if (py == 0) adj_pass<SWC, false, true>(t, s0, SW, ln, a);
+            else adj_pass<SWC, true, true>(t, s0, SW, ln, a);
+            if (py == 0 && px == 0) {
+#pragma unroll
+                for (int i = 0; i < PRW; ++i) acc[i] = t.ac[i];
+            } else {
+                // the border pixel itself is its own mirror image: M(0) has no second copy of row / column 0
+                const bool xr0 = py == 1 && r0 == 0, xr7 = py == 2 && r0 == TH - PRW;
+                const bool xcx = px == 1 && cp == 0, xcy = px == 2 && cp == 31;
+#pragma unroll
+                for (int i = 0; i < PRW; ++i) {
+                    const bool xr = (i == 0 && xr0) || (i == PRW - 1 && xr7);
+                    acc[i].x += (xr || xcx) ? 0.0f : t.ac[i].x;
+                    acc[i].y += (xr || xcy) ? 0.0f : t.ac[i].y;
+                }
+            }
+        }
+    }
+    // epilogue: plain gradient, or clamp gate + -b * (coef * g + extra) into g_model_out[:, :c]
+    const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)((h0 + r0) * a.w + w0 + 2 * cp);
+    if constexpr (EPI) {
+        const float nv = a.norm_in ? a.norm_in[n] : s_red[0];
+        const float coef = norm_coef_dev(nv, a.scale, a.power), mb = -a.k.b;
+        if (own_norm && a.norm_out && ch == 0 && ty == 0 && tx == 0 && threadIdx.x == 0) a.norm_out[n] = nv;
+        const uint8_t *ip = a.inside_r + (int64_t)plane * hw + o;
+        const float *ep = a.g_extra ? a.g_extra + (int64_t)plane * hw + o : nullptr;
+        float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
+        uchar2 in[PRW];
+        v2f ex[PRW];
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) {
+            in[i] = *reinterpret_cast<const uchar2 *>(ip + (unsigned)(i * a.w));
+            ex[i] = ep ? *reinterpret_cast<const v2f *>(ep + (unsigned)(i * a.w)) : v2f{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) {
+            v2f gq;
+            gq.x = in[i].x ? mb * (coef * acc[i].x + ex[i].x) : 0.0f;
+            gq.y = in[i].y ? mb * (coef * acc[i].y + ex[i].y) : 0.0f;
+            *reinterpret_cast<v2f *>(gp + (unsigned)(i * a.w)) = gq;
+        }
+    } else {
+        float *gp = a.out + (int64_t)plane * hw + o;
+#pragma unroll
+        for (int i = 0; i < PRW; ++i) *reinterpret_cast<v2f *>(gp + (unsigned)(i * a.w)) = acc[i];
     }
 }
 
@@ -712,7 +1015,6 @@ __global__ __launch_bounds__(NT) void k_blur_fold4(FoldArgs f)
 // =====================================================================
 // host dispatch
 // =====================================================================
-constexpr size_t kScratchBytes = 1024;
 static inline size_t sep_lds_bytes(int rr)
 {
     return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes;
@@ -823,11 +1125,13 @@ static void set_taps(const dpsx_op *op, BlurArgs &a)
     for (int k = 0; k < 4; ++k) a.nrun[k] = op->nrun[k];
 }
 
-// compile-time LDS row-stride classes of the 16-byte-load variants (0 = runtime stride, the scalar-load variants)
+// compile-time LDS row-stride classes of the 16-byte-load variants (0 = runtime stride, the scalar-load variants):
+// multiples of 4 words (16-byte staging stores) that are NOT multiples of 32 (run_apply_col reads one column of 16 rows)
+constexpr int kSwNarrow = 100, kSwWide = 132;
 static inline int taps_swc(const TapGeom &g, bool vec)
 {
     const int rw = TW + g.l + g.r;
-    return !vec ? 0 : (rw <= 96 ? 96 : 128);
+    return !vec ? 0 : (rw <= 96 ? kSwNarrow : kSwWide);
 }
 static inline size_t taps_lds(const TapGeom &g, int swc)
 {
@@ -855,8 +1159,8 @@ template <bool POST, int MODE>
 static int launch_taps(const BlurArgs &a, const TapGeom &g, bool vec, hipStream_t s)
 {
     if (!vec) return launch_taps_k<POST, MODE, false, 0>(a, g, s);
-    if (taps_swc(g, true) == 96) return launch_taps_k<POST, MODE, true, 96>(a, g, s);
-    return launch_taps_k<POST, MODE, true, 128>(a, g, s);
+    if (taps_swc(g, true) == kSwNarrow) return launch_taps_k<POST, MODE, true, kSwNarrow>(a, g, s);
+    return launch_taps_k<POST, MODE, true, kSwWide>(a, g, s);
 }
 
 template <bool POST, bool RESID>
@@ -875,10 +1179,32 @@ int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h,
     return ((planes * (h + 2 * r4) * (w + 2 * r4) * 4 + 255) / 256) * 256;
 }
 
+template <bool EPI, int SWC>
+static int launch_taps_adj1_k(const BlurArgs &a, const TapGeom &g, const AdjReach &reach, hipStream_t s)
+{
+    const size_t lds = taps_lds(g, SWC);
+    DPSX_LAUNCH((k_blur_taps_adj<EPI, SWC>), grid_blocks(a), lds, s, a, g, reach);
+}
+
+// regular geometry: one launch on the image domain (k_blur_taps_adj)
+template <bool EPI>
+static int launch_taps_adj1(const dpsx_op *op, BlurArgs a, hipStream_t s)
+{
+    a.runs = static_cast<const TapRun *>(op->d_runs_adj);
+    for (int k = 0; k < 4; ++k) a.nrun[k] = op->nrun[k];
+    // negated offsets: the forward halos swap sides; at least 11 zero rows / 4 zero columns for the clamped mirrored windows
+    const AdjReach reach{op->halo_b, op->halo_t, op->halo_r, op->halo_l};
+    const TapGeom g = make_geom(std::max(reach.t, 11), std::max(reach.b, 11), std::max(reach.l, 4), std::max(reach.r, 4));
+    if (taps_swc(g, true) == kSwNarrow) return launch_taps_adj1_k<EPI, kSwNarrow>(a, g, reach, s);
+    return launch_taps_adj1_k<EPI, kSwWide>(a, g, reach, s);
+}
+
 template <bool EPI>
 static int launch_taps_adj(const dpsx_op *op, BlurArgs a, bool vec, float *scratch, int64_t scratch_bytes,
                            hipStream_t s)
 {
+    if (vec && a.h % TH == 0 && a.w % TW == 0 && (!EPI || (aligned16(a.g_extra) && (reinterpret_cast<uintptr_t>(a.inside_r) & 3u) == 0)))
+        return launch_taps_adj1<EPI>(op, a, s);
     const int r4 = op->radius4;
     const int ph = a.h + 2 * r4, pw = a.w + 2 * r4;
     if (!scratch || scratch_bytes < (int64_t)a.planes * ph * pw * 4) return DPSX_EWORKSPACE;

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -202,6 +203,11 @@ int dpsx_op_create_blur(const float *kernel_host, int ks, int mode, dpsx_op **ou
             }
         std::vector<TapRun> fwd, adj;
         for (int c = 0; c < 4; ++c) {
+            std::stable_sort(cls_a[c].begin(), cls_a[c].end(), [](const TapRun &x, const TapRun &y) { return x.dx > y.dx; });
+            for (const TapRun &t : cls_a[c]) {
+                op->nrun_adj_pos[c] += t.dx >= 1;
+                op->nrun_adj_neg[c] += t.dx <= -1;
+            }
             op->nrun[c] = (int)cls_f[c].size();
             fwd.insert(fwd.end(), cls_f[c].begin(), cls_f[c].end());
             adj.insert(adj.end(), cls_a[c].begin(), cls_a[c].end());

@@ -55,6 +55,7 @@ struct BlurArgs {
     // [even dx, 4 taps | even dx, 2 taps | odd dx, 4 taps | odd dx, 2 taps]; nrun[k] = runs in class k
     const TapRun *runs;
     int nrun[4];
+    int nhlo[4], nhhi[4];  // one-launch adjoint: runs [nhlo, nhhi) of class k can reach this tile's mirrored-column strip
     int dbg;   // phase-ablation mask: 0 unless built with -DDPSX_ABLATION=1 (see blur_sep.h)
     // zero-extended loads (adjoint): the source plane is src_h x src_w and sits at (src_off, src_off)
     // inside the h x w domain the kernel tiles (src_off = 0 and src = domain for everything else)
@@ -752,34 +753,42 @@ __device__ __forceinline__ void adj_pass(TapAcc &t, const float *s0, const int S
 // layout with one `ds_bpermute` per value (same wave, no barrier, no LDS storage).  Row groups of a half-wave are 4 (8)
 // rows apart: with the 100 / 132-word strides their 8-byte reads fall on disjoint bank ranges.
 // The strip is wide enough that its outermost column pair's neighbour contributes nothing (reach <= 2 W - 2).
-template <int SWC, bool RY, int PR>
-__device__ __forceinline__ void adj_strip_pass(v2f (&acc)[PRW], const float *s0, const int SW, AdjLane ln, const BlurArgs &a,
-                                               const int py, const int px, const int cy, const int cx, const int wr0,
-                                               const int r0)
+template <int PR>
+struct StripLane { int cps, row_s, cp_base, cp; };
+
+template <int PR>
+__device__ __forceinline__ StripLane<PR> strip_lane(const int px, const int wr0)
 {
     constexpr int W = PR == 2 ? 8 : 16, NH = 32 / W;          // column pairs per strip row; row groups per half-wave
     const int lane = threadIdx.x & 63;
-    const int cps = lane & (W - 1), k = lane / W, half = k / NH, j = k % NH;
-    const int row_s = wr0 + j * (2 * PRW / NH) + half * PR;     // first of the lane's PR rows (tile coordinates)
-    const int cp_base = px == 2 ? 32 - W : 0, cp = cp_base + cps;
-    ln.rb = RY ? cy - row_s - (PR - 1) : row_s;
-    ln.cb = cx - 2 * cp - 1;
-    ln.cbo = cx - 2 * cp;
-    TapAccT<PR> t;
-    adj_all_runs<SWC, RY, true, PR>(t, s0, SW, ln, a);
+    StripLane<PR> sl;
+    const int k = lane / W, half = k / NH, j = k % NH;
+    sl.cps = lane & (W - 1);
+    sl.row_s = wr0 + j * (2 * PRW / NH) + half * PR;            // first of the lane's PR rows (tile coordinates)
+    sl.cp_base = px == 2 ? 32 - W : 0;
+    sl.cp = sl.cp_base + sl.cps;
+    return sl;
+}
+
+// merge the strip's shifted set, drop the self-mirrored border pixel, hand the values to the owner lanes of the plain layout
+template <int PR>
+__device__ __forceinline__ void strip_finish(v2f (&acc)[PRW], TapAccT<PR> &t, const StripLane<PR> &sl, const int py,
+                                             const int px, const int wr0, const int r0)
+{
+    constexpr int W = PR == 2 ? 8 : 16;
 #pragma unroll
     for (int i = 0; i < PR; ++i) {
         const float nb = __shfl_down(t.aco[i].x, 1, kWave);
         t.ac[i].x += t.aco[i].y;
-        t.ac[i].y += cps == W - 1 ? 0.0f : nb;
+        t.ac[i].y += sl.cps == W - 1 ? 0.0f : nb;
         // the border pixel itself is its own mirror image
-        const int trow = row_s + i;
+        const int trow = sl.row_s + i;
         const bool xr = (py == 1 && trow == 0) || (py == 2 && trow == TH - 1);
-        if (xr || (px == 1 && cp == 0)) t.ac[i].x = 0.0f;
-        if (xr || (px == 2 && cp == 31)) t.ac[i].y = 0.0f;
+        if (xr || (px == 1 && sl.cp == 0)) t.ac[i].x = 0.0f;
+        if (xr || (px == 2 && sl.cp == 31)) t.ac[i].y = 0.0f;
     }
-    // back to the plain layout: owner lane (column pair cpo, rows r0 .. r0 + 7) pulls row rho = r0 - wr0 + i of the strip
-    const int rel = (int)(threadIdx.x & 31) - cp_base;
+    // owner lane (column pair cpo, rows r0 .. r0 + 7) pulls row rho = r0 - wr0 + i of the strip
+    const int rel = (int)(threadIdx.x & 31) - sl.cp_base;
     const bool mine = rel >= 0 && rel < W;
 #pragma unroll
     for (int i = 0; i < PRW; ++i) {
@@ -790,6 +799,169 @@ __device__ __forceinline__ void adj_strip_pass(v2f (&acc)[PRW], const float *s0,
         acc[i].x += mine ? vx : 0.0f;
         acc[i].y += mine ? vy : 0.0f;
     }
+}
+
+// ---------------------------------------------------------------- one scan of the table for the whole tile
+// The passes above each walk the run table again, and a walk costs its fixed per-run latency whether the pass has 32 or 8
+// FMAs per run to show for it: the occupancy probe (tools/occ_taps.sh) gives T = 55 + 174 / n us for n resident workgroups
+// per CU against 30 + 78 / n for the plain operator -- the adjoint's per-tile serial path was 2.2x as long.  A tile with at
+// most one mirrored side per axis (every tile of an image with two or more tiles per axis) therefore applies, per run and
+// in ONE iteration: the plain window, the mirrored-row window (into the same accumulators: the self-mirrored border row is
+// restored from a saved copy), the mirrored-column strip window and the corner strip window.
+struct FusedLane {
+    // plain window
+    int rb, cb, cbo, rb63, dyl, dyh, dxl, dxh;
+    // mirrored rows, plain layout (wave-uniform switch v_on)
+    bool v_on, v_x0, v_x7, v_xc;
+    int v_rb, v_rb63, v_dyl, v_dyh;
+    // mirrored columns / corner: strip layout
+    bool h_on, vh_on;
+    int h_rb, vh_rb, h_cb, h_cbo, h_dxl, h_dxh;
+    int h_lo[4], h_hi[4];      // per class: the runs a strip on this side can use (adjoint table sorted by dx)
+    int row_lo, row_hi, col_lo, col_hi;
+};
+
+// window reads and FMAs as separate steps, so that the windows of one run are read behind ONE wait
+template <int L, int PR>
+struct Win { v2f w[PR + L - 1]; };
+
+template <int L, int PR>
+__device__ __forceinline__ void win_read(Win<L, PR> &x, const float *p, const int SW)
+{
+#pragma unroll
+    for (int m = 0; m < PR + L - 1; ++m) x.w[m] = *(LdsPair)(p + m * SW);
+}
+
+template <int L, bool REV, bool SWAP, int PR>
+__device__ __forceinline__ void win_fma(v2f (&acc)[PR], const Win<L, PR> &x, const TapRun &r)
+{
+#pragma unroll
+    for (int q = 0; q < L; ++q) {
+        const v2f w2 = v2f{r.w[q], r.w[q]};
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+            const v2f in = SWAP ? v2f{x.w[i + q].y, x.w[i + q].x} : x.w[i + q];
+            v2f &dst = acc[REV ? PR - 1 - i : i];
+            dst = __builtin_elementwise_fma(w2, in, dst);
+        }
+    }
+}
+
+// HASV / HASH: the wave has a mirrored-row window / the tile a mirrored-column strip (and then, with HASV, the corner
+// strip) -- wave-uniform, hoisted out of the loop.  No liveness tests inside: a run that cannot reach the image from
+// these rows reads a window of staged zeros (that is what the clamps guarantee) and adds exact zeros.
+template <int L, bool ODD, int SWC, int PRS, bool HASV, bool HASH>
+__device__ __forceinline__ void adj_runs_fused(TapAcc &t, TapAccT<PRS> &h, TapAccT<PRS> &vh, const float *s0,
+                                               const int sw_rt, const FusedLane &g, const TapRun *runs, const int nruns)
+{
+    const int SW = SWC > 0 ? SWC : sw_rt;
+    if (nruns <= 0) return;
+    TapRun r = load_run(runs, 0);
+    for (int k = 0; k < nruns; ++k) {
+        const TapRun nxt = load_run(runs, min(k + 1, nruns - 1));
+        v2f (&dst)[PRW] = ODD ? t.aco : t.ac;
+        int hcol = 0;
+        {   // plain window (+ column 63 of the shifted set) and the mirrored-column strip: one wait
+            Win<L, PRW> wm;
+            Win<L, PRS> wh;
+            float c[L];
+            win_read<L, PRW>(wm, s0 + (g.rb + r.dy0) * SW + (ODD ? g.cbo : g.cb) + r.dx, SW);
+            if constexpr (ODD) {
+                const float *p63 = s0 + (g.rb63 + r.dy0) * SW + 63 + r.dx;
+#pragma unroll
+                for (int q = 0; q < L; ++q) c[q] = (*(LdsPair)(p63 + q * SW)).x;
+            }
+            if constexpr (HASH) {
+                hcol = min(max((ODD ? g.h_cb : g.h_cbo) + r.dx, g.col_lo), g.col_hi - 2);
+                win_read<L, PRS>(wh, s0 + (g.h_rb + r.dy0) * SW + hcol, SW);
+            }
+            win_fma<L, false, false, PRW>(dst, wm, r);
+            if constexpr (ODD) {
+#pragma unroll
+                for (int q = 0; q < L; ++q) t.c63 = fmaf(r.w[q], c[q], t.c63);
+            }
+            if constexpr (HASH) win_fma<L, false, true, PRS>(ODD ? h.ac : h.aco, wh, r);
+        }
+        if constexpr (HASV) {   // mirrored rows (same accumulators; the self-mirrored border row is put back) + corner strip
+            Win<L, PRW> wv;
+            Win<L, PRS> wc;
+            float c[L];
+            const int row = min(max(g.v_rb + r.dy0, g.row_lo), g.row_hi - (PRW + L - 1));
+            win_read<L, PRW>(wv, s0 + row * SW + (ODD ? g.cbo : g.cb) + r.dx, SW);
+            if constexpr (ODD) {
+                const int r63 = min(max(g.v_rb63 + r.dy0, g.row_lo), g.row_hi - L);
+                const float *p63 = s0 + r63 * SW + 63 + r.dx;
+#pragma unroll
+                for (int q = 0; q < L; ++q) c[q] = (*(LdsPair)(p63 + q * SW)).x;
+            }
+            if constexpr (HASH) {
+                const int rowc = min(max(g.vh_rb + r.dy0, g.row_lo), g.row_hi - (PRS + L - 1));
+                win_read<L, PRS>(wc, s0 + rowc * SW + hcol, SW);
+            }
+            const v2f s0v = dst[0], s7v = dst[PRW - 1];
+            win_fma<L, true, false, PRW>(dst, wv, r);
+            if (g.v_x0) dst[0] = s0v;                 // the border row is its own mirror image
+            if (g.v_x7) dst[PRW - 1] = s7v;
+            if constexpr (ODD) {
+                const float sc = t.c63;
+#pragma unroll
+                for (int q = 0; q < L; ++q) t.c63 = fmaf(r.w[q], c[q], t.c63);
+                if (g.v_xc) t.c63 = sc;
+            }
+            if constexpr (HASH) win_fma<L, true, true, PRS>(ODD ? vh.ac : vh.aco, wc, r);
+        }
+        r = nxt;
+    }
+}
+
+// one class of the table: the adjoint table is sorted by dx inside a class, so the runs a left (right) strip can use are
+// its first (last) ones -- up to three segments, the middle one with the strip windows
+template <int L, bool ODD, int SWC, int PRS>
+__device__ __forceinline__ void adj_class_fused(TapAcc &t, TapAccT<PRS> &h, TapAccT<PRS> &vh, const float *s0, const int SW,
+                                                const FusedLane &g, const TapRun *runs, const int n, const int hlo,
+                                                const int hhi)
+{
+#pragma unroll 1
+    for (int seg = 0; seg < 3; ++seg) {
+        const int lo = seg == 0 ? 0 : (seg == 1 ? hlo : hhi), hi = seg == 0 ? hlo : (seg == 1 ? hhi : n);
+        if (hi <= lo) continue;
+        const bool hs = seg == 1;
+        if (g.v_on) {                                  // wave-uniform
+            if (hs) adj_runs_fused<L, ODD, SWC, PRS, true, true>(t, h, vh, s0, SW, g, runs + lo, hi - lo);
+            else adj_runs_fused<L, ODD, SWC, PRS, true, false>(t, h, vh, s0, SW, g, runs + lo, hi - lo);
+        } else {
+            if (hs) adj_runs_fused<L, ODD, SWC, PRS, false, true>(t, h, vh, s0, SW, g, runs + lo, hi - lo);
+            else adj_runs_fused<L, ODD, SWC, PRS, false, false>(t, h, vh, s0, SW, g, runs + lo, hi - lo);
+        }
+    }
+}
+
+template <int SWC, int PRS>
+__device__ __forceinline__ void adj_fused(v2f (&acc)[PRW], const float *s0, const int SW, FusedLane &g, const BlurArgs &a,
+                                          const int py, const int px, const int cy, const int cx, const int wr0,
+                                          const int r0)
+{
+    const StripLane<PRS> sl = strip_lane<PRS>(px, wr0);
+    g.h_rb = sl.row_s;
+    g.vh_rb = cy - sl.row_s - (PRS - 1);
+    g.h_cb = cx - 2 * sl.cp - 1;
+    g.h_cbo = cx - 2 * sl.cp;
+    TapAcc t;
+    TapAccT<PRS> h, vh;
+    tapacc_zero(t); tapacc_zero(h); tapacc_zero(vh);
+    const TapRun *r = a.runs;
+    adj_class_fused<4, false, SWC, PRS>(t, h, vh, s0, SW, g, r, a.nrun[0], g.h_lo[0], g.h_hi[0]);
+    r += a.nrun[0];
+    adj_class_fused<2, false, SWC, PRS>(t, h, vh, s0, SW, g, r, a.nrun[1], g.h_lo[1], g.h_hi[1]);
+    r += a.nrun[1];
+    adj_class_fused<4, true, SWC, PRS>(t, h, vh, s0, SW, g, r, a.nrun[2], g.h_lo[2], g.h_hi[2]);
+    r += a.nrun[2];
+    adj_class_fused<2, true, SWC, PRS>(t, h, vh, s0, SW, g, r, a.nrun[3], g.h_lo[3], g.h_hi[3]);
+    merge_shifted(t);
+#pragma unroll
+    for (int i = 0; i < PRW; ++i) acc[i] = t.ac[i];
+    if (g.h_on) strip_finish<PRS>(acc, h, sl, 0, px, wr0, r0);          // block-uniform
+    if (g.vh_on) strip_finish<PRS>(acc, vh, sl, py, px, wr0, r0);        // wave-uniform
 }
 
 template <bool EPI, int SWC>
@@ -824,6 +996,35 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, 
     TapAcc t;
     AdjLane ln;
     ln.row_lo = -g.t; ln.row_hi = TH + g.b; ln.col_lo = -g.l; ln.col_hi = TW + g.r;
+    // at most one mirrored side per axis, strip wide enough: one scan of the table (adj_fused)
+    const int hrch = lef ? reach.r : reach.l;
+    const bool fused = !(top && bot) && !(lef && rig) && !((lef || rig) && hrch > 30) && !ABL(4);      // block-uniform
+    if (fused) {
+        const int py = top ? 1 : (bot ? 2 : 0), px = (lef && reach.r >= 1) ? 1 : ((rig && reach.l >= 1) ? 2 : 0);
+        const int cy = py == 2 ? CM : 0, cx = px == 2 ? CM : 0;
+        FusedLane f;
+        f.row_lo = ln.row_lo; f.row_hi = ln.row_hi; f.col_lo = ln.col_lo; f.col_hi = ln.col_hi;
+        f.rb = r0; f.cb = 2 * cp; f.cbo = 2 * cp - 1; f.rb63 = wr0 + l15;
+        f.dyl = -h0 - wr0 - (2 * PRW - 1); f.dyh = a.h - 1 - h0 - wr0;
+        f.dxl = -w0 - (TW - 1); f.dxh = a.w - 1 - w0;
+        f.v_on = (py == 1 && max(wr0, 1) <= reach.b) || (py == 2 && min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1) >= -reach.t);
+        f.v_on = f.v_on && !ABL(1);
+        f.v_rb = cy - r0 - (PRW - 1); f.v_rb63 = cy - (wr0 + l15);
+        f.v_dyl = py == 1 ? max(wr0, 1) : -BIG;
+        f.v_dyh = py == 1 ? BIG : min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1);
+        f.v_x0 = py == 1 && r0 == 0; f.v_x7 = py == 2 && r0 == TH - PRW;
+        f.v_xc = (py == 1 && wr0 + l15 == 0) || (py == 2 && wr0 + l15 == TH - 1);
+        f.h_on = px != 0 && !ABL(2);
+        f.vh_on = f.h_on && f.v_on;
+        f.h_dxl = px == 1 ? 1 : -BIG; f.h_dxh = px == 1 ? BIG : -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f.h_lo[c] = px == 1 ? 0 : a.nrun[c] - a.nhhi[c];        // left: the first nhlo runs (dx >= 1); right: the last nhhi
+            f.h_hi[c] = px == 1 ? a.nhlo[c] : a.nrun[c];
+            if (!f.h_on) f.h_hi[c] = f.h_lo[c] = 0;
+        }
+        adj_fused<SWC, 4>(acc, s0, SW, f, a, py, px, cy, cx, wr0, r0);
+    } else
 #pragma unroll 1
     for (int py = 0; py < 3; ++py) {
         // rows: plain | mirrored about the top border (image row 0) | about the bottom border (image row h - 1)
@@ -845,19 +1046,6 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, 
             ln.cbo = px ? cx - 2 * cp : 2 * cp - 1;
             ln.dxl = px == 0 ? -w0 - (TW - 1) : (px == 1 ? 1 : -BIG);
             ln.dxh = px == 0 ? a.w - 1 - w0 : (px == 1 ? BIG : -1);
-            if (px) {
-                const int rch = px == 1 ? reach.r : reach.l;
-                if (rch <= 14) {
-                    if (py == 0) adj_strip_pass<SWC, false, 2>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
-                    else adj_strip_pass<SWC, true, 2>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
-                    continue;
-                }
-                if (rch <= 30) {
-                    if (py == 0) adj_strip_pass<SWC, false, 4>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
-                    else adj_strip_pass<SWC, true, 4>(acc, s0, SW, ln, a, py, px, cy, cx, wr0, r0);
-                    continue;
-                }
-            }
             if (py == 0 && px == 0) adj_pass<SWC, false, false>(t, s0, SW, ln, a);
             else if (px == 0) adj_pass<SWC, true, false>(t, s0, SW, ln, a);
             else if (py == 0) adj_pass<SWC, false, true>(t, s0, SW, ln, a);
@@ -1136,7 +1324,12 @@ static inline int taps_swc(const TapGeom &g, bool vec)
 static inline size_t taps_lds(const TapGeom &g, int swc)
 {
     const int rh = TH + g.t + g.b, sw = swc > 0 ? swc : TW + g.l + g.r;
-    return ((size_t)rh * sw) * 4 + kScratchBytes;
+    size_t pad = 0;
+#if defined(DPSX_ABLATION) && DPSX_ABLATION
+    static const size_t env_pad = getenv("DPSX_LDS_PAD") ? (size_t)atoi(getenv("DPSX_LDS_PAD")) : 0;   // occupancy probe
+    pad = env_pad;
+#endif
+    return ((size_t)rh * sw) * 4 + kScratchBytes + pad;
 }
 static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
@@ -1191,7 +1384,11 @@ template <bool EPI>
 static int launch_taps_adj1(const dpsx_op *op, BlurArgs a, hipStream_t s)
 {
     a.runs = static_cast<const TapRun *>(op->d_runs_adj);
-    for (int k = 0; k < 4; ++k) a.nrun[k] = op->nrun[k];
+    for (int k = 0; k < 4; ++k) {
+        a.nrun[k] = op->nrun[k];
+        a.nhlo[k] = op->nrun_adj_pos[k];      // (as counts: runs with dx >= 1 lead the class, runs with dx <= -1 end it)
+        a.nhhi[k] = op->nrun_adj_neg[k];
+    }
     // negated offsets: the forward halos swap sides; at least 11 zero rows / 4 zero columns for the clamped mirrored windows
     const AdjReach reach{op->halo_b, op->halo_t, op->halo_r, op->halo_l};
     const TapGeom g = make_geom(std::max(reach.t, 11), std::max(reach.b, 11), std::max(reach.l, 4), std::max(reach.r, 4));

@@ -357,6 +357,9 @@ struct dpsx_op {
     void *d_runs_fwd = nullptr, *d_runs_adj = nullptr;
     int nruns = 0;
     int nrun[4] = {0, 0, 0, 0};           // runs per class (even/odd dx) x (4/2 taps), in table order
+    // the ADJOINT table is sorted by dx, descending, inside each class: its first nrun_adj_pos[c] runs have dx >= 1 (the only
+    // ones a left-border strip can use), its last nrun_adj_neg[c] have dx <= -1 (right border)
+    int nrun_adj_pos[4] = {0, 0, 0, 0}, nrun_adj_neg[4] = {0, 0, 0, 0};
     // halo the tap list actually needs on each side of a tile (rows as they are, columns rounded up to 4): a motion
     // path usually leaves the centre in one direction, so this is about half of radius4 per axis
     int halo_t = 0, halo_b = 0, halo_l = 0, halo_r = 0;

@@ -625,21 +625,41 @@ int dpsx_update_f32(const float *sample, const float *g_a, const float *g_b, flo
 // ------------------------------------------------------------------ best-of-N
 // Residual partials per block (one launch; two for the operators that materialise A x first), then one small launch
 // that finishes costs[p] and, when asked, the combine with the previous costs and the argmin over all particles.
-static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, int l1, const float *prev,
-                      int potential, float *raw_out, float *costs, int64_t *best_idx, float *best_val, int64_t n,
-                      int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream,
-                      float *replicate_to = nullptr)
+// the scoring launch of one contiguous range of particles (partial sums only; finalize_select finishes them)
+static int score_launch(dpsx_op *op, const Ws &ws, const float *x, const float *y, int64_t y_n, int l1, int parts,
+                        int64_t n, int64_t c, int64_t h, int64_t w, hipStream_t s)
 {
-    int rc = check_geom(op, n, c, h, w);
-    if (rc != DPSX_OK) return rc;
-    if (!x || !y || !costs || (y_n != 1 && y_n != n)) return DPSX_EINVAL;
-    if (n == 0) return best_idx ? DPSX_EINVAL : DPSX_OK;
-    Ws ws;
-    if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    int parts = (int)parts_per_particle(op, c, h, w);
-    if (op->kind == OP_IDENT || op->kind == OP_MASK || op->kind == OP_PHASE) parts = 64;
     const int64_t chw = c * h * w;
+    const Tail tail{};                     // no in-launch tail
+    int rc;
+    switch (op->kind) {
+    case OP_SEP:
+    case OP_TAPS: return blur_score(op, x, y, y_n, ws.partials, n, c, h, w, l1, tail, s);
+    case OP_RESIZE: return resize_score(op, x, y, y_n, ws.partials, n, c, l1, tail, s);
+    case OP_IDENT: return residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s, l1, tail);
+    case OP_MASK:
+    case OP_PHASE: {
+        // A x into scratch, then the generic residual reduction
+        const int64_t m = meas_elems(op, c, h, w);
+        float *ax = ws.meas;
+        if (op->kind == OP_MASK) rc = mask_mul(x, op->mask, ax, n * c, h * w, s);
+        else rc = phase_forward(op, x, ax, nullptr, n * c, ws.priv, ws.priv_bytes, s);
+        if (rc != DPSX_OK) return rc;
+        return residual_partials(y, y_n, ax, nullptr, ws.partials, n, m, parts, s, l1, tail);
+    }
+    default: return DPSX_EUNSUPPORTED;
+    }
+}
+
+static int score_parts(const dpsx_op *op, int64_t c, int64_t h, int64_t w)
+{
+    if (op->kind == OP_IDENT || op->kind == OP_MASK || op->kind == OP_PHASE) return 64;
+    return (int)parts_per_particle(op, c, h, w);
+}
+
+static Tail score_tail(const Ws &ws, int parts, int l1, const float *prev, int potential, float *raw_out, float *costs,
+                       int64_t *best_idx, float *best_val, int64_t n, int64_t chw)
+{
     // the reduction is finished by one small follow-up launch (finalize_select), not inside the scoring launch: see
     // the measurement at k_finalize_select
     Tail fin{};
@@ -654,35 +674,23 @@ static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, 
     fin.best_idx = best_idx;
     fin.best_val = best_val;
     fin.n = (int)n;
-    const Tail tail{};                     // no in-launch tail
-    switch (op->kind) {
-    case OP_SEP:
-    case OP_TAPS: rc = blur_score(op, x, y, y_n, ws.partials, n, c, h, w, l1, tail, s); break;
-    case OP_RESIZE: rc = resize_score(op, x, y, y_n, ws.partials, n, c, l1, tail, s); break;
-    case OP_IDENT:
-        rc = residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s, l1, tail);
-        break;
-    case OP_MASK:
-    case OP_PHASE: {
-        // A x into scratch, then the generic residual reduction
-        const int64_t m = meas_elems(op, c, h, w);
-        float *ax = ws.meas;
-        if (op->kind == OP_MASK) rc = mask_mul(x, op->mask, ax, n * c, h * w, s);
-        else rc = phase_forward(op, x, ax, nullptr, n * c, ws.priv, ws.priv_bytes, s);
-        if (rc != DPSX_OK) return rc;
-        rc = residual_partials(y, y_n, ax, nullptr, ws.partials, n, m, parts, s, l1, tail);
-        break;
-    }
-    default: return DPSX_EUNSUPPORTED;
-    }
+    return fin;
+}
+
+static int score_impl(dpsx_op *op, const float *x, const float *y, int64_t y_n, int l1, const float *prev,
+                      int potential, float *raw_out, float *costs, int64_t *best_idx, float *best_val, int64_t n,
+                      int64_t c, int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_geom(op, n, c, h, w);
     if (rc != DPSX_OK) return rc;
-    if (replicate_to) {
-        // search step: costs + select, then dst[p] = x[best].  Measured and dropped: both in one launch (every block
-        // redoing the small reduction out of LDS before it copies its slice): 92.5 us per step against 89.3, N = 64.
-        if ((rc = finalize_select(fin, s)) != DPSX_OK) return rc;
-        return gather_f32(x, best_idx, replicate_to, n, n, chw, true, s);
-    }
-    return finalize_select(fin, s);
+    if (!x || !y || !costs || (y_n != 1 && y_n != n)) return DPSX_EINVAL;
+    if (n == 0) return best_idx ? DPSX_EINVAL : DPSX_OK;
+    Ws ws;
+    if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int parts = score_parts(op, c, h, w);
+    if ((rc = score_launch(op, ws, x, y, y_n, l1, parts, n, c, h, w, s)) != DPSX_OK) return rc;
+    return finalize_select(score_tail(ws, parts, l1, prev, potential, raw_out, costs, best_idx, best_val, n, c * h * w), s);
 }
 
 int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise, const float *y,
@@ -695,14 +703,23 @@ int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, 
     if (!x_t || !model_out || !y || !sample || !costs || !best_idx_dev || !coefs_host) return DPSX_EINVAL;
     if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
     if ((y_n != 1 && y_n != n) || n == 0 || x_next == sample) return DPSX_EINVAL;
-    // S1 (no x0_hat store) -> scoring launch -> one launch for costs + select (+ the winner's replication).
-    // Measured and dropped: S1 fused into the separable scoring kernel (the proposal's halo needs all four input
-    // streams: 72 us for the fused launch against 37 + 30 for the two, N = 64).
-    rc = posterior_fwd(x_t, model_out, noise, nullptr, sample, nullptr, n, c * h * w, to_coefs(coefs_host),
-                       (hipStream_t)stream);
+    // S1 (no x0_hat store) -> scoring launch -> one launch for costs + select -> the winner's replication.
+    // Measured and dropped (N = 64, Gaussian, 89.7 us for this sequence): S1 fused into the separable scoring kernel (the
+    // proposal's halo needs all four input streams: 72 us for the fused launch against 37 + 30 for the two); costs +
+    // select + replication in one launch (92.5 us per step); the particles in 2 / 3 / 4 chunks with the (latency-bound)
+    // scoring of chunk k on a second stream beside the (bandwidth-bound) S1 of chunk k + 1, forked and joined by events:
+    // 94.8 / 100.8 / 113.6 us -- the cross-stream dependencies cost more than the overlap returns.
+    Ws ws;
+    if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t chw = c * h * w;
+    const int parts = score_parts(op, c, h, w);
+    rc = posterior_fwd(x_t, model_out, noise, nullptr, sample, nullptr, n, chw, to_coefs(coefs_host), s);
     if (rc != DPSX_OK) return rc;
-    return score_impl(op, sample, y, y_n, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, c, h, w,
-                      workspace, workspace_bytes, stream, x_next);
+    if ((rc = score_launch(op, ws, sample, y, y_n, 0, parts, n, c, h, w, s)) != DPSX_OK) return rc;
+    rc = finalize_select(score_tail(ws, parts, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, chw), s);
+    if (rc != DPSX_OK || !x_next) return rc;
+    return gather_f32(sample, best_idx_dev, x_next, n, n, chw, true, s);
 }
 
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,

@@ -1205,7 +1205,12 @@ __global__ __launch_bounds__(NT) void k_blur_fold4(FoldArgs f)
 // =====================================================================
 static inline size_t sep_lds_bytes(int rr)
 {
-    return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes;
+    size_t pad = 0;
+#if defined(DPSX_ABLATION) && DPSX_ABLATION
+    static const size_t env_pad = getenv("DPSX_LDS_PAD") ? (size_t)atoi(getenv("DPSX_LDS_PAD")) : 0;   // occupancy probe
+    pad = env_pad;
+#endif
+    return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes + pad;
 }
 
 static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int64_t w)

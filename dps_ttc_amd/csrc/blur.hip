@@ -438,8 +438,12 @@ struct RunClip {          // zero-extended sources (adjoint): the source plane's
 // loads plus per-lane selects -- 2.5x the VALU instructions of the FMAs themselves (measured: SQ_INSTS_VALU).
 // Measured and dropped in round 2 (plain forward, N = 64, 50.5 us with this loop): two runs per iteration behind one
 // wait (52.4), the table in LDS with a software-pipelined loop (next window's reads issued before this run's FMAs: 57.2),
-// the table in VGPRs broadcast with v_readlane_b32 (61-83: the selects end up in VGPRs).  An ablation build shows the
-// record fetches themselves cost 1.4 us; what the loop is short of is waves per SIMD (LDS admits four workgroups per CU).
+// the table in VGPRs broadcast with v_readlane_b32 (61-83: the selects end up in VGPRs), and a pipeline around ONE explicit
+// s_waitcnt lgkmcnt(0) per run placed BEFORE the next window's reads are issued, so that the FMAs run on data that has
+// already arrived (55.5; the ISA had exactly the intended wait / read / FMA order).  An ablation build shows the record
+// fetches themselves cost 1.4 us.  By the counters the launch is bound by no single pipe: VALU ~25 us, LDS ~16 us and the
+// 20 us load / store phases of a tile add up with little overlap (occupancy probe: T = 30 + 78 / n us for n workgroups
+// per CU, n = 5 here).
 typedef const __attribute__((address_space(4))) TapRun *ConstRuns;
 __device__ __forceinline__ TapRun load_run(const TapRun *runs, int i)
 {

@@ -45,8 +45,8 @@ ALGO_P = {
 KERNELS = {
     "gaussian_blur": {"fwd": "S1 + A(x0_hat) + residual + norm partials (k_blur_sep_fwd<3,POST,RESID>)",
                       "bwd": "A^T + clamp gate + -b*coef (k_blur_sep_adj<3,EPI>)"},
-    "motion_blur": {"fwd": "S1 + tap-list A(x0_hat) + residual + norm partials (k_blur_taps_fwd<POST,RESID>)",
-                    "bwd": "tap-list correlation-transpose + reflection fold + gate (k_blur_taps_corrT + k_blur_fold4<EPI>)"},
+    "motion_blur": {"fwd": "S1 + tap-list A(x0_hat) + residual + norm partials (k_blur_taps<POST,RESID>)",
+                    "bwd": "tap-list A^T on the image domain: plain + mirrored windows in one scan, gate, -b*coef (k_blur_taps_adj<EPI>)"},
     "super_resolution": {"fwd": "S1 + resize W,H passes + residual + norm partials (k_resize_rows_fwd<POST,RESID>)",
                          "bwd": "resize adjoint (inverse tables) + clamp gate + -b*coef (k_resize_adj<EPI>)"},
     "inpainting": {"fwd": "S1 + mask residual + norm partials (k_mask_step_fwd)",

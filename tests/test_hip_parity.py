@@ -918,16 +918,30 @@ def test_in_launch_reduction_sees_fresh_partials(K, name, hw, n):
 
 
 @pytest.mark.parametrize("hw", [(128, 192), (192, 128), (256, 256), (128, 128)])
-@pytest.mark.parametrize("kind,seed", [("motion", 2), ("motion", 7), ("gauss_taps", 0), ("wide", 0)])
+@pytest.mark.parametrize("kind,seed", [("motion", 2), ("motion", 7), ("gauss_taps", 0), ("wide", 0), ("widest", 0), ("onesided", 3)])
 def test_taps_regular_multi_tile(K, oracle, kind, seed, hw):
-    """tap-list operator on regular multi-tile images (loads-first stage, clipped ring tiles of the padded-domain
-    adjoint) for kernels of different reach -- a short path, the 25 x 25 Gaussian as a tap list (reach 12), and a
-    kernel that reaches 29 px on every side -- against the oracle, plus <A x, u> = <x, A^T u>"""
+    """tap-list operator on regular multi-tile images (loads-first stage; the one-launch adjoint: plain + mirrored-row
+    windows, mirrored-column / corner strips in one scan of the run table) for kernels of different reach -- a short
+    path, the 25 x 25 Gaussian as a tap list (reach 12), a kernel that reaches 29 px on every side (16-pair strips), a
+    65 x 65 kernel that reaches 32 px (beyond the strips: the multi-pass fallback) and a kernel whose taps all lie on one
+    side of the centre (empty strip ranges) -- against the oracle, plus <A x, u> = <x, A^T u>"""
     rng = np.random.RandomState(seed + hw[0])
     if kind == "motion":
         k2 = synthetic_motion_kernel(61, seed)
     elif kind == "gauss_taps":
         k2 = oracle.tables.gaussian_kernel2d(61, 3.0).astype(np.float32)
+    elif kind == "widest":
+        k2 = np.zeros((65, 65), dtype=np.float32)
+        idx = rng.randint(0, 65, size=(48, 2))
+        k2[idx[:, 0], idx[:, 1]] = rng.rand(48).astype(np.float32)
+        k2[0, 0] = k2[64, 64] = k2[0, 64] = k2[64, 0] = 0.3
+        k2[32, 0] = k2[0, 31] = 0.2
+        k2 /= k2.sum()
+    elif kind == "onesided":
+        k2 = np.zeros((61, 61), dtype=np.float32)
+        idx = np.stack([rng.randint(31, 50, size=30), rng.randint(8, 30, size=30)], axis=1)     # dy > 0, dx < 0 only
+        k2[idx[:, 0], idx[:, 1]] = rng.rand(30).astype(np.float32)
+        k2 /= k2.sum()
     else:
         k2 = np.zeros((61, 61), dtype=np.float32)
         idx = rng.randint(1, 60, size=(40, 2))

@@ -1207,14 +1207,15 @@ __global__ __launch_bounds__(NT) void k_blur_fold4(FoldArgs f)
 // =====================================================================
 // host dispatch
 // =====================================================================
-static inline size_t sep_lds_bytes(int rr)
+// small: only the reduction slots (regular multi-tile geometry: no slow folds, which keep 160 tap words in the scratch)
+static inline size_t sep_lds_bytes(int rr, bool small_scratch = false)
 {
     size_t pad = 0;
 #if defined(DPSX_ABLATION) && DPSX_ABLATION
     static const size_t env_pad = getenv("DPSX_LDS_PAD") ? (size_t)atoi(getenv("DPSX_LDS_PAD")) : 0;   // occupancy probe
     pad = env_pad;
 #endif
-    return (size_t)((TH + 2 * rr) * ((TW + 2 * rr + 4 + 15) / 16 * 16)) * 4 + kScratchBytes + pad;
+    return (size_t)((TH + 2 * rr) * (TW + 2 * rr + 4)) * 4 + (small_scratch ? 256 : kScratchBytes) + pad;
 }
 
 static void fill_geometry(BlurArgs &a, int64_t planes, int64_t c, int64_t h, int64_t w)
@@ -1290,7 +1291,8 @@ static int dispatch_sep_fwd(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 template <int R4, bool EPI>
 static int launch_sep_adj(const BlurArgs &a, const SepTaps &t, int reach, hipStream_t s)
 {
-    const size_t lds = sep_lds_bytes(4 * R4);
+    // two or more full tiles per axis: every fold is a fast (register-window) fold and the scratch holds one norm slot
+    const size_t lds = sep_lds_bytes(4 * R4, a.h % TH == 0 && a.w % TW == 0 && a.tiles_x >= 2 && a.tiles_y >= 2);
     DPSX_LAUNCH((k_blur_sep_adj<R4, EPI>), grid_blocks(a), lds, s, a, t, reach);
 }
 

@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
     ap.add_argument("--operator", default="gaussian_blur", choices=sorted(ALGO_P))
+    ap.add_argument("--chains", type=int, default=2,
+                    help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -245,15 +247,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    x = x_t
-    for i in range(args.warmup):
-        x = step(i, x)
-    dd.global_best_of_n_device(buf.norm.clone(), x, counts)        # warm the select (and the collectives) too
+    # ---- the timed loop runs the N particles as `chains` independent groups, each with its own operator handle and
+    # buffers on its own HIP stream: the three launches of a step are dependent, the groups are not, so the
+    # bandwidth-bound launch of one group runs beside the arithmetic-bound launch of another (DESIGN.md, section 5:
+    # inside one chain the load / compute / store phases of the tile kernels add up).  Per-particle results do not
+    # depend on the grouping (tests/test_driver_gpu.py checks it bit for bit).
+    nch = args.chains if args.chains >= 1 and n % max(args.chains, 1) == 0 else 1
+    m = n // nch
+    groups = []
+    for j in range(nch):
+        if nch == 1:
+            gop, ghandle, gbuf, gstream = op, handle, buf, torch.cuda.current_stream()
+        else:
+            gop, _ = build_operator(args.operator, device)
+            ghandle = gop.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else gop.hip_handle(x_t)
+            gbuf = kernels.StepBuffers(ghandle, m, 3, 256, 256, device)
+            gstream = torch.cuda.Stream(device=device)
+        sl = slice(j * m, (j + 1) * m)
+        groups.append({"op": gop, "handle": ghandle, "buf": gbuf, "stream": gstream, "x": x_t[sl],
+                       "ring": [{k: v[sl] for k, v in s.items()} for s in ring]})
+
+    def group_step(g, i, timers=None):
+        ck = smp.step_coefs[999 - (i % 1000)]
+        s = g["ring"][i % len(ring)]
+        if timers is not None:
+            timers[0].record()
+        kernels.step_fwd(g["handle"], g["buf"], g["x"], s["model_out"], s["noise"], y, ck)
+        if timers is not None:
+            timers[1].record()
+        kernels.step_bwd(g["handle"], g["buf"], y, spec["scale"], spec["power"], ck)
+        if timers is not None:
+            timers[2].record()
+        g["x"] = kernels.step_update(g["buf"], s["g_unet"], ck)
+        if timers is not None:
+            timers[3].record()
+
+    def run_steps(first, count, timers=None):
+        for i in range(count):
+            for j, g in enumerate(groups):
+                with torch.cuda.stream(g["stream"]):
+                    group_step(g, first + i, timers[i] if timers is not None and j == 0 else None)
+
+    def join_groups():
+        cur = torch.cuda.current_stream()
+        for g in groups:
+            cur.wait_stream(g["stream"])
+        if nch == 1:
+            return groups[0]["buf"].norm, groups[0]["x"]
+        return torch.cat([g["buf"].norm for g in groups]), torch.cat([g["x"] for g in groups])
+
+    for g in groups:
+        g["stream"].wait_stream(torch.cuda.current_stream())
+    run_steps(0, args.warmup)
+    norm_all, x_all = join_groups()
+    dd.global_best_of_n_device(norm_all.clone(), x_all, counts)        # warm the select (and the collectives) too
     barrier()
+    for g in groups:
+        g["stream"].wait_stream(torch.cuda.current_stream())
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        x = step(args.warmup + i, x)
-    winner, best_dev = dd.global_best_of_n_device(buf.norm, x, counts)   # final best-of-N over all ranks' particles
+    run_steps(args.warmup, args.steps)
+    norm_all, x_all = join_groups()
+    winner, best_dev = dd.global_best_of_n_device(norm_all, x_all, counts)   # final best-of-N over all ranks' particles
     barrier()
     elapsed = time.perf_counter() - t0
     best = int(best_dev)
@@ -261,15 +315,33 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    x = x_t
 
-    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
+    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region: ONE chain of all N particles,
+    # launches back to back with nothing beside them
     reps = min(args.steps, 50)
+    if nch > 1:
+        for i in range(5):          # the one-chain buffers have not been touched yet
+            x = step(i, x)
+        torch.cuda.synchronize()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps):
         x = step(args.warmup + args.steps + i, x, evs[i])
     torch.cuda.synchronize()
     dur = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) * 1e-3
            for j, k in enumerate(("fwd", "bwd", "upd"))}
+    # ... and the same launches as the timed loop runs them: group 0's (N / chains particles) on its own stream while the
+    # other groups' launches run beside them (longer per launch, shorter per step)
+    dur_grouped = None
+    if nch > 1:
+        for g in groups:
+            g["stream"].wait_stream(torch.cuda.current_stream())
+        gev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+        run_steps(args.warmup + args.steps, reps, gev)
+        join_groups()
+        torch.cuda.synchronize()
+        dur_grouped = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in gev])) * 1e3
+                       for j, k in enumerate(("fwd", "bwd", "upd"))}
 
     # ---- on-box copy ceiling (report against the vendor peak AND a measured copy kernel):
     # a 1 GiB device-to-device copy, read + write bytes over its event time
@@ -308,6 +380,9 @@ def main():
                     "algorithmic_bytes_per_launch": algo[dom] * n,
                     "avg_launch_ms": dur[dom] * 1e3,
                     "all_launches_ms": {k: v * 1e3 for k, v in dur.items()},
+                    "launch_timing": "one chain of all N particles, launches back to back, HIP events on the launch "
+                                     "stream, outside the timed region",
+                    "grouped_launches_us": dur_grouped,
                     "step_algorithmic_bytes_per_particle": step_p * P_BYTES,
                     "step_frac_of_hbm_roofline": (step_p * P_BYTES * n / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
                     "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs}
@@ -331,7 +406,9 @@ def main():
                                    f"best-of-N N={n}/GPU, DDPM t cycling 999->0",
                        "operator": args.operator, "particles_per_gpu": n, "global_particles": total,
                        "image": "3x256x256",
-                       "parallelism": f"particles sharded x{world}, champion all-gather at the select"},
+                       "chains_per_gpu": nch,
+                       "parallelism": f"particles sharded x{world}; per GPU {nch} independent particle group(s), one HIP "
+                                      f"stream each; champion all-gather at the select"},
             "roofline": roofline,
             "best_of_n_index": best,
         }

@@ -168,3 +168,53 @@ def test_bench_self_launch_two_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_particles"] == 8 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and 0 <= rec["best_of_n_index"] < 8 and "roofline" in rec
+
+
+@pytest.mark.parametrize("operator", ["gaussian_blur", "motion_blur"])
+def test_particle_groups_on_streams_match_one_chain(operator):
+    """bench.py's timed loop runs the particles as independent groups on separate HIP streams (own operator handle and
+    buffers each): per-particle results must not depend on the grouping -- x_{t-1} and the distances bit for bit."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from dps_ttc_amd import kernels
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    dev = torch.device("cuda", 0)
+    smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                         rescale_timesteps=True, timestep_respacing="")
+    n, steps = 6, 4
+    x_t, ring, truth, meas_noise = bench.synth_inputs(n, 2, dev, 77)
+
+    def make(count):
+        op, fkw = bench.build_operator(operator, dev)
+        handle = op.hip_handle(x_t)
+        return op, handle, kernels.StepBuffers(handle, count, 3, 256, 256, dev)
+
+    op, handle, buf = make(n)
+    y = (op.forward(truth.to(dev)).detach() + meas_noise.to(dev)[..., :256, :256]).contiguous()
+
+    def run(handle, buf, x, sl, stream):
+        with torch.cuda.stream(stream):
+            for i in range(steps):
+                ck = smp.step_coefs[999 - 300 * i]
+                s = ring[i % 2]
+                kernels.step_fwd(handle, buf, x, s["model_out"][sl], s["noise"][sl], y, ck)
+                kernels.step_bwd(handle, buf, y, 0.3, 1, ck)
+                x = kernels.step_update(buf, s["g_unet"][sl], ck)
+        return x
+
+    ref = run(handle, buf, x_t, slice(0, n), torch.cuda.current_stream()).clone()
+    ref_norm = buf.norm.clone()
+    outs = []
+    for j in range(2):
+        _, h2, b2 = make(n // 2)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream())
+        sl = slice(j * n // 2, (j + 1) * n // 2)
+        outs.append((run(h2, b2, x_t[sl], sl, st), b2, st))
+    for _, _, st in outs:
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o[0] for o in outs]), ref)
+    assert torch.equal(torch.cat([o[1].norm for o in outs]), ref_norm)

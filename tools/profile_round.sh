@@ -19,6 +19,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_wri
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $OUT/${TAG}_rdreq -- python3 tools/kbench.py --only fwd,bwd,upd --reps 5 > /dev/null 2> $OUT/${TAG}_rdreq.err
 python3 tools/parse_pmc.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_stats $OUT/${TAG}_rdreq > $OUT/${TAG}_traffic_summary.json
 cp $(ls $OUT/${TAG}_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+# the same trace split by grid size: one chain of N particles (what roofline.avg_launch_ms is measured on) vs the timed
+# loop's groups of N / chains particles, which run beside each other on their own streams
+python3 tools/trace_by_grid.py $OUT/${TAG}_stats > $OUT/${TAG}_bench_kernel_trace_by_grid.csv
 {
   echo "# tools/kbench.py / tools/kbench_search.py on MI355X, N=64, 256x256, us per launch of the fused step (avg and min over 30)"
   for op in gaussian_blur super_resolution inpainting motion_blur phase_retrieval; do
@@ -32,6 +35,7 @@ cp $(ls $OUT/${TAG}_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_kerne
 } > $OUT/${TAG}_operators_kbench.txt
 python3 bench.py --steps 200 --warmup 20 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1_20steps.json 2>> $OUT/${TAG}_bench_n1.err
+python3 bench.py --steps 200 --warmup 20 --chains 1 --no-cpu-baseline > $OUT/${TAG}_bench_n1_one_chain.json 2>> $OUT/${TAG}_bench_n1.err
 for op in motion_blur super_resolution inpainting phase_retrieval; do
   python3 bench.py --operator $op --steps 100 --warmup 10 --cpu-steps 2 --cpu-particles 16 > $OUT/${TAG}_bench_${op}.json 2>> $OUT/${TAG}_bench_n1.err
 done

@@ -191,9 +191,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must match")
 
+    # one hardware queue per HIP stream: with the runtime's default of 4 the particle groups' streams, the null stream
+    # and RCCL's can end up sharing queues (seen once as a 2.4x slower step with three groups); must be set before the
+    # HIP runtime initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     import torch.distributed as dist
+    shared_gpu = world > max(torch.cuda.device_count(), 1)
     local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -253,6 +258,8 @@ def main():
     # inside one chain the load / compute / store phases of the tile kernels add up).  Per-particle results do not
     # depend on the grouping (tests/test_driver_gpu.py checks it bit for bit).
     nch = args.chains if args.chains >= 1 and n % max(args.chains, 1) == 0 else 1
+    if shared_gpu:
+        nch = 1         # rank processes time-slicing ONE GPU (gloo rehearsal): several queues per process make it crawl
     m = n // nch
     groups = []
     for j in range(nch):

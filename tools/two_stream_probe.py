@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--chains", type=int, default=2)
+    ap.add_argument("--offset", action="store_true",
+                    help="chain j starts j launches into its step (K1 of one group beside K2 / K3 of the other)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -37,12 +39,21 @@ def main():
         buf = kernels.StepBuffers(handle, n, 3, 256, 256, dev)
         return dict(op=op, handle=handle, buf=buf, x=x_t, ring=ring, y=y)
 
-    def step(c, i):
+    def launch(c, i, which):
         ck = smp.step_coefs[999 - (i % 1000)]
         s = c["ring"][i % 3]
-        kernels.step_fwd(c["handle"], c["buf"], c["x"], s["model_out"], s["noise"], c["y"], ck)
-        kernels.step_bwd(c["handle"], c["buf"], c["y"], 0.3, 1, ck)
-        c["x"] = kernels.step_update(c["buf"], s["g_unet"], ck)
+        if which == 0:
+            kernels.step_fwd(c["handle"], c["buf"], c["x"], s["model_out"], s["noise"], c["y"], ck)
+        elif which == 1:
+            kernels.step_bwd(c["handle"], c["buf"], c["y"], 0.3, 1, ck)
+        else:
+            c["x"] = kernels.step_update(c["buf"], s["g_unet"], ck)
+
+    def step(c, i):
+        # a chain with offset o enqueues launches o .. o+2 of the sequence K1 K2 K3 K1 ...: same work per call, shifted
+        o = c.get("offset", 0)
+        for q in range(o, o + 3):
+            launch(c, i + q // 3, q % 3)
 
     def run(chains, streams):
         for i in range(20):
@@ -64,6 +75,11 @@ def main():
     print(f"1 chain  x {n:3d} particles: {t1 * 1e6:7.1f} us/step  {n / t1 / 1e3:7.1f} k particle-steps/s")
     k = args.chains
     many = [make(n // k, 1234 + j) for j in range(k)]
+    if args.offset:
+        for j, c in enumerate(many):
+            c["offset"] = j % 3
+            for q in range(c["offset"]):          # run the launches the shifted sequence skips at its start
+                launch(c, 0, q)
     streams = [torch.cuda.Stream() for _ in range(k)]
     tk = run(many, streams)
     print(f"{k} chains x {n // k:3d} particles: {tk * 1e6:7.1f} us/step  {n / tk / 1e3:7.1f} k particle-steps/s")

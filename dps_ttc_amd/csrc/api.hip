@@ -637,13 +637,13 @@ static int score_launch(dpsx_op *op, const Ws &ws, const float *x, const float *
     case OP_TAPS: return blur_score(op, x, y, y_n, ws.partials, n, c, h, w, l1, tail, s);
     case OP_RESIZE: return resize_score(op, x, y, y_n, ws.partials, n, c, l1, tail, s);
     case OP_IDENT: return residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s, l1, tail);
-    case OP_MASK:
+    case OP_MASK:      // y - mask * x in the reduction itself (one launch, no scratch)
+        return residual_partials(y, y_n, x, nullptr, ws.partials, n, chw, parts, s, l1, tail, op->mask, h * w);
     case OP_PHASE: {
         // A x into scratch, then the generic residual reduction
         const int64_t m = meas_elems(op, c, h, w);
         float *ax = ws.meas;
-        if (op->kind == OP_MASK) rc = mask_mul(x, op->mask, ax, n * c, h * w, s);
-        else rc = phase_forward(op, x, ax, nullptr, n * c, ws.priv, ws.priv_bytes, s);
+        rc = phase_forward(op, x, ax, nullptr, n * c, ws.priv, ws.priv_bytes, s);
         if (rc != DPSX_OK) return rc;
         return residual_partials(y, y_n, ax, nullptr, ws.partials, n, m, parts, s, l1, tail);
     }

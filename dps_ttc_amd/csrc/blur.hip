@@ -814,13 +814,13 @@ __device__ __forceinline__ void strip_finish(v2f (&acc)[PRW], TapAccT<PR> &t, co
 // restored from a saved copy), the mirrored-column strip window and the corner strip window.
 struct FusedLane {
     // plain window
-    int rb, cb, cbo, rb63, dyl, dyh, dxl, dxh;
+    int rb, cb, cbo, rb63;
     // mirrored rows, plain layout (wave-uniform switch v_on)
     bool v_on, v_x0, v_x7, v_xc;
-    int v_rb, v_rb63, v_dyl, v_dyh;
+    int v_rb, v_rb63;
     // mirrored columns / corner: strip layout
     bool h_on, vh_on;
-    int h_rb, vh_rb, h_cb, h_cbo, h_dxl, h_dxh;
+    int h_rb, vh_rb, h_cb, h_cbo;
     int h_lo[4], h_hi[4];      // per class: the runs a strip on this side can use (adjoint table sorted by dx)
     int row_lo, row_hi, col_lo, col_hi;
 };
@@ -1009,18 +1009,13 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, 
         FusedLane f;
         f.row_lo = ln.row_lo; f.row_hi = ln.row_hi; f.col_lo = ln.col_lo; f.col_hi = ln.col_hi;
         f.rb = r0; f.cb = 2 * cp; f.cbo = 2 * cp - 1; f.rb63 = wr0 + l15;
-        f.dyl = -h0 - wr0 - (2 * PRW - 1); f.dyh = a.h - 1 - h0 - wr0;
-        f.dxl = -w0 - (TW - 1); f.dxh = a.w - 1 - w0;
         f.v_on = (py == 1 && max(wr0, 1) <= reach.b) || (py == 2 && min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1) >= -reach.t);
         f.v_on = f.v_on && !ABL(1);
         f.v_rb = cy - r0 - (PRW - 1); f.v_rb63 = cy - (wr0 + l15);
-        f.v_dyl = py == 1 ? max(wr0, 1) : -BIG;
-        f.v_dyh = py == 1 ? BIG : min(wr0 + 2 * PRW - 1, TH - 2) - (TH - 1);
         f.v_x0 = py == 1 && r0 == 0; f.v_x7 = py == 2 && r0 == TH - PRW;
         f.v_xc = (py == 1 && wr0 + l15 == 0) || (py == 2 && wr0 + l15 == TH - 1);
         f.h_on = px != 0 && !ABL(2);
         f.vh_on = f.h_on && f.v_on;
-        f.h_dxl = px == 1 ? 1 : -BIG; f.h_dxh = px == 1 ? BIG : -1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             f.h_lo[c] = px == 1 ? 0 : a.nrun[c] - a.nhhi[c];        // left: the first nhlo runs (dx >= 1); right: the last nhhi

@@ -439,7 +439,8 @@ int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const flo
 int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_t hw, hipStream_t s);
 // sums of squares of (y - ax) per particle in `parts` chunks -> partials[n*parts]; r optional
 int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials,
-                      int64_t n, int64_t m, int parts, hipStream_t s, int l1 = 0, const Tail &tail = Tail{});
+                      int64_t n, int64_t m, int parts, hipStream_t s, int l1 = 0, const Tail &tail = Tail{},
+                      const float *mask = nullptr, int64_t hw = 0);
 int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipStream_t s);
 // one small launch: per-particle values from the partials (t.partials / parts / mode / prev / potential -> raw_out, out)
 // and, if t.best_idx, the torch.argmin-order select over them (t.counters is not used)

@@ -167,21 +167,37 @@ int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_
 
 // ===================================================================== residual + norm
 // grid (parts, n): block (q, p) reduces elements [q*chunk, (q+1)*chunk) of particle p.
+// mask (nullable, hw elements, broadcast over particles and channels): the inpainting operator applied on the fly,
+// d = y - mask * ax with the product rounded once, exactly as mask_mul + this kernel did in two launches (the search
+// step's scoring of a masked proposal: 44 -> one launch without the 2P round trip through scratch).
 __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__restrict__ y, int64_t y_n,
                                                                 const float *__restrict__ ax,
                                                                 float *__restrict__ r,
                                                                 float *__restrict__ partials, int64_t m,
-                                                                int64_t chunk, int l1, Tail tail)
+                                                                int64_t chunk, int l1, Tail tail,
+                                                                const float *__restrict__ mask, int hw)
 {
     __shared__ float scratch[kThreads / kWave];
     const int64_t p = blockIdx.y, q = blockIdx.x;
     const float *yp = y + (y_n == 1 ? 0 : p) * m, *ap = ax + p * m;
     const int64_t lo = q * chunk, hi = min(m, lo + chunk);
     float acc = 0.0f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-        const float d = __fsub_rn(yp[i], ap[i]);
-        if (r) r[p * m + i] = d;
-        acc = l1 ? acc + fabsf(d) : fmaf(d, d, acc);
+    if (mask) {
+        int mi = (int)((lo + threadIdx.x) % hw);                 // walks the mask plane with the element index
+        const int step = kThreads % hw;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const float d = __fsub_rn(yp[i], __fmul_rn(ap[i], mask[mi]));
+            if (r) r[p * m + i] = d;
+            acc = l1 ? acc + fabsf(d) : fmaf(d, d, acc);
+            mi += step;
+            if (mi >= hw) mi -= hw;
+        }
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const float d = __fsub_rn(yp[i], ap[i]);
+            if (r) r[p * m + i] = d;
+            acc = l1 ? acc + fabsf(d) : fmaf(d, d, acc);
+        }
     }
     const float t = block_sum(acc, scratch);
     if (threadIdx.x == 0) tail_publish(&partials[p * gridDim.x + q], t);
@@ -189,13 +205,15 @@ __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__r
 }
 
 int residual_partials(const float *y, int64_t y_n, const float *ax, float *r, float *partials, int64_t n,
-                      int64_t m, int parts, hipStream_t s, int l1, const Tail &tail)
+                      int64_t m, int parts, hipStream_t s, int l1, const Tail &tail, const float *mask, int64_t hw)
 {
     if (n == 0) return DPSX_OK;
+    if (mask && (hw < 1 || hw > (1 << 30))) return DPSX_EINVAL;
     const int64_t chunk = (m + parts - 1) / parts;
     Tail t = tail;
     t.blocks_per_particle = parts;
-    k_residual_partials<<<dim3(parts, (unsigned)n), kThreads, 0, s>>>(y, y_n, ax, r, partials, m, chunk, l1, t);
+    k_residual_partials<<<dim3(parts, (unsigned)n), kThreads, 0, s>>>(y, y_n, ax, r, partials, m, chunk, l1, t, mask,
+                                                                     (int)hw);
     return check_launch();
 }
 

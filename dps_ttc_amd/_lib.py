@@ -71,6 +71,8 @@ SIGNATURES = {
     "dpsx_score_argmin_f32": (c_int, [c_void_p, _f, _f, _i64, _f, _p, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "dpsx_search_step_f32": (c_int, [c_void_p, _f, _f, _f, _f, _i64, _f, _f, _p, _f, _f, _i64, _i64, _i64, _i64,
                                      POINTER(Coefs), _p, _i64, _p]),
+    "dpsx_search_step_one_f32": (c_int, [c_void_p, _f, _f, _f, _f, _i64, _f, _f, _p, _f, _f, _i64, _i64, _i64, _i64,
+                                         POINTER(Coefs), _p, _i64, _p]),
     "dpsx_resample_cost_f32": (c_int, [c_void_p, _f, _f, _i64, _f, c_int, _f, _f, _i64, _i64, _i64, _i64, _p, _i64, _p]),
     "dpsx_argmin_f32": (c_int, [_f, _i64, _p, _f, _p]),
     "dpsx_gather_f32": (c_int, [_f, _p, _f, _i64, _i64, _i64, _p]),

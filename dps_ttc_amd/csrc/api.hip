@@ -722,6 +722,34 @@ int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, 
     return gather_f32(sample, best_idx_dev, x_next, n, n, chw, true, s);
 }
 
+int dpsx_search_step_one_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise, const float *y,
+                             int64_t y_n, float *sample, float *costs, int64_t *best_idx_dev, float *best_val_dev,
+                             float *x_next, int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
+                             void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_geom(op, n, c, h, w);
+    if (rc != DPSX_OK) return rc;
+    if (!x_t || !model_out || !y || !sample || !costs || !best_idx_dev || !coefs_host) return DPSX_EINVAL;
+    if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
+    if ((y_n != 1 && y_n != n) || n == 0 || x_next == sample || x_next == x_t) return DPSX_EINVAL;
+    // After a select every particle of SearchDDPM is a copy of the winner (img[best_path.repeat(n_paths)], :633), so the
+    // loop's state is ONE particle: S1 reads that state and its model output once for all n proposals (the per-particle
+    // noise makes them differ), the scoring launch and the select are the n-particle ones, and the winner is copied out
+    // once instead of n times: 3P of traffic per particle-step (noise in, proposal out, proposal scored) instead of the
+    // 8P of the replicated form -- and one model evaluation per step instead of n for the caller.
+    Ws ws;
+    if ((rc = carve(op, workspace, workspace_bytes, n, c, h, w, ws)) != DPSX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t chw = c * h * w;
+    const int parts = score_parts(op, c, h, w);
+    rc = posterior_fwd(x_t, model_out, noise, nullptr, sample, nullptr, n, chw, to_coefs(coefs_host), s, true);
+    if (rc != DPSX_OK) return rc;
+    if ((rc = score_launch(op, ws, sample, y, y_n, 0, parts, n, c, h, w, s)) != DPSX_OK) return rc;
+    rc = finalize_select(score_tail(ws, parts, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, chw), s);
+    if (rc != DPSX_OK || !x_next) return rc;
+    return gather_f32(sample, best_idx_dev, x_next, 1, n, chw, true, s);
+}
+
 int dpsx_score_f32(dpsx_op *op, const float *x, const float *y, int64_t y_n, float *costs, int64_t n, int64_t c,
                    int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream)
 {

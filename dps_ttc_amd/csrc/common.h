@@ -432,8 +432,9 @@ int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n,
                  int64_t n, int64_t c, int l1, const Tail &tail, hipStream_t s);
 
 // elementwise.hip
+// one_state: x [1, chw] and mo [1, 2 chw] feed all n particles (z, x0, sample, inside stay per particle)
 int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, float *sample, uint8_t *inside,
-                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
+                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s, bool one_state = false);
 int posterior_bwd(const float *g_x0, const float *g_s, const float *x, const float *mo, const float *z,
                   float *g_x, float *g_mo, int64_t n, int64_t chw, const Coefs &k, hipStream_t s);
 int mask_mul(const float *x, const float *mask, float *y, int64_t planes, int64_t hw, hipStream_t s);

@@ -23,12 +23,14 @@ __global__ __launch_bounds__(kThreads) void k_posterior_fwd(const float *__restr
                                                             const float *__restrict__ mo,
                                                             const float *__restrict__ z,
                                                             float *__restrict__ x0o, float *__restrict__ so,
-                                                            uint8_t *__restrict__ ins, int64_t chw, Coefs k)
+                                                            uint8_t *__restrict__ ins, int64_t chw, Coefs k,
+                                                            int64_t xs)
 {
+    // xs: particle stride of x (and half that of model_out): chw, or 0 when ONE state feeds all particles (search_ddpm)
     const int64_t p = blockIdx.y;
     const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * (VEC ? 4 : 1);
     if (i >= chw) return;
-    const float *xp = x + p * chw + i, *ep = mo + p * 2 * chw + i, *vp = ep + chw;
+    const float *xp = x + p * xs + i, *ep = mo + p * 2 * xs + i, *vp = ep + chw;
     const int64_t o = p * chw + i;
     if constexpr (VEC) {
         const float4 xv = *reinterpret_cast<const float4 *>(xp);
@@ -62,15 +64,16 @@ __global__ __launch_bounds__(kThreads) void k_posterior_fwd(const float *__restr
 }
 
 int posterior_fwd(const float *x, const float *mo, const float *z, float *x0, float *sample, uint8_t *inside,
-                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s)
+                  int64_t n, int64_t chw, const Coefs &k, hipStream_t s, bool one_state)
 {
     if (n == 0 || chw == 0) return DPSX_OK;
+    const int64_t xs = one_state ? 0 : chw;
     const bool vec = chw % 4 == 0 && aligned16(x) && aligned16(mo) && aligned16(z) && aligned16(x0) &&
                      aligned16(sample) && (reinterpret_cast<uintptr_t>(inside) & 3u) == 0;
     if (vec)
-        k_posterior_fwd<true><<<grid_for(chw / 4, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k);
+        k_posterior_fwd<true><<<grid_for(chw / 4, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k, xs);
     else
-        k_posterior_fwd<false><<<grid_for(chw, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k);
+        k_posterior_fwd<false><<<grid_for(chw, n), kThreads, 0, s>>>(x, mo, z, x0, sample, inside, chw, k, xs);
     return check_launch();
 }
 

@@ -164,11 +164,12 @@ class GlobalSelect:
     local champion, the winner is picked on the device from the gathered (min, rank) table.
     Every rank holds at least one particle (the loop runs a batch per rank)."""
 
-    def __call__(self, costs_local, particles_local):
+    def __call__(self, costs_local, particles_local, n_out=None):
+        """-> n_out copies of the global winner (default: one per local particle)"""
         rank, world = _world()
+        n = particles_local.shape[0] if n_out is None else int(n_out)
         if world == 1:
-            return kernels.replicate(particles_local, kernels.argmin(costs_local))
-        n = particles_local.shape[0]
+            return kernels.replicate(particles_local, kernels.argmin(costs_local), n_out=n)
         if particles_local.is_cuda:
             local_best, local_min = kernels.argmin(costs_local, want_value=True)
             champ = kernels.replicate(particles_local, local_best, n_out=1)

@@ -449,8 +449,14 @@ class SearchDDPM(DDPM):
     (reference :592-641).  Scoring, argmin and the winner's replication are HIP; the winner's index
     never leaves the device."""
 
-    #: optional hook for multi-GPU runs: callable(costs_local, particles_local) -> particles_local
+    #: optional hook for multi-GPU runs: callable(costs_local, particles_local, n_out=None) -> n_out copies of the
+    #: global winner (default: as many as particles_local)
     global_select = None
+    #: After a select every particle is a copy of the winner (reference :633), so from the second step on the loop keeps
+    #: ONE state particle: one model evaluation per step instead of N, S1 reads the state once for all N proposals, the
+    #: winner is copied out once (dpsx_search_step_one_f32).  Results are those of the replicated form (the per-particle
+    #: noise draws, costs and winner indices are the same); False keeps N copies as the reference does.
+    single_state = True
 
     def search_step(self, model, img, idx, measurement, handle, noise=None):
         with torch.no_grad():
@@ -466,6 +472,20 @@ class SearchDDPM(DDPM):
             return self.global_select(costs, sample), costs
         return x_next, costs
 
+    def search_step_one(self, model, state, n, idx, measurement, handle, noise=None):
+        """One step from the single state particle `state` [1,C,H,W] -> (winner [1,C,H,W], costs [n])."""
+        with torch.no_grad():
+            model_out = self._call_model(model, state, idx)
+        if noise is None:
+            noise = self._randn(torch.empty((n,) + tuple(state.shape[1:]), dtype=torch.float32, device=state.device))
+        local = self.global_select is None
+        winner, sample, costs, best, _ = handle.search_step_one(state, model_out, noise, measurement,
+                                                                self.step_coefs[idx], want_winner=local)
+        self.last_best = best
+        if not local:
+            winner = self.global_select(costs, sample, n_out=1)
+        return winner, costs
+
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, operator,
                       potential_type='min', resample_every_steps=10, rs_temp=0.1, **kwargs):
         img = x_start.detach()
@@ -475,10 +495,19 @@ class SearchDDPM(DDPM):
         mask = kwargs.get('mask', None)
         handle = operator.hip_handle_for(mask) if operator.name == 'inpainting' else operator.hip_handle(img)
         self.best_paths, self.best_costs = [], []
+        n = img.shape[0]
+        state = None                      # the single state particle, once a select has made all particles equal
         for idx in range(self.num_timesteps - 1, -1, -1):
-            img, costs = self.search_step(model, img, idx, measurement, handle)
+            if state is None:
+                img, costs = self.search_step(model, img, idx, measurement, handle)
+                if self.single_state and n > 1:
+                    state = img[:1]
+            else:
+                state, costs = self.search_step_one(model, state, n, idx, measurement, handle)
             if kwargs.get('trace', False):
                 self.best_costs.append(costs)
+        if state is not None:             # the reference returns N copies of the final winner
+            return state.repeat(n, 1, 1, 1)
         return img.clone()
 
     @torch.no_grad()

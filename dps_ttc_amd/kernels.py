@@ -226,6 +226,30 @@ class OpHandle:
                                          ws.numel(), stream_of(x_t)), "dpsx_search_step_f32")
         return x_next, sample, costs, best, val
 
+    def search_step_one(self, x_one, model_out_one, noise, y, coefs, want_winner=True):
+        """The same step from ONE state particle (after a select all particles are copies of the winner): x_one
+        [1,C,H,W], model_out_one [1,2C,H,W], noise [N,C,H,W] -> (winner [1,C,H,W] or None, sample [N,...], costs,
+        best, costs[best]).  Bit-identical to search_step on N copies of the state; one model evaluation per step."""
+        x_one, model_out_one, y = _nchw(f32c(x_one, "x_t")), f32c(model_out_one, "model_out"), f32c(y, "measurement")
+        noise = _nchw(f32c(noise, "noise"))
+        n, c, h, w = noise.shape
+        if n == 0:
+            raise ValueError("best-of-N over an empty particle set")
+        if x_one.shape != (1, c, h, w) or model_out_one.shape[0] != 1 or model_out_one[0].numel() != 2 * c * h * w:
+            raise ValueError(f"one state particle expected: x {tuple(x_one.shape)}, model_out {tuple(model_out_one.shape)}, "
+                             f"noise {tuple(noise.shape)}")
+        sample = torch.empty_like(noise)
+        winner = torch.empty_like(x_one) if want_winner else None
+        costs = torch.empty(n, dtype=torch.float32, device=noise.device)
+        best = torch.empty((), dtype=torch.int64, device=noise.device)
+        val = torch.empty(1, dtype=torch.float32, device=noise.device)
+        ws = self.workspace(n, c, h, w, noise.device)
+        check(lib().dpsx_search_step_one_f32(self._h, ptr(x_one), ptr(model_out_one), ptr(noise), ptr(y), y.shape[0],
+                                             ptr(sample), ptr(costs), ptr(best), ptr(val), ptr(winner), n, c, h, w,
+                                             byref(coefs), ptr(ws), ws.numel(), stream_of(noise)),
+              "dpsx_search_step_one_f32")
+        return winner, sample, costs, best, val
+
     def resample_cost(self, x, y, prev_costs=None, potential_type='min'):
         """SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585) in one launch:
         curr[p] = ||y - A(x_p)||_1^2 / (C H W), net = combine(curr, prev_costs) -> (curr, net)."""

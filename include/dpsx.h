@@ -206,6 +206,16 @@ int dpsx_search_step_f32(dpsx_op *op, const float *x_t, const float *model_out, 
                          int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same step with the loop's state held as ONE particle (gaussian_diffusion.py:618-633): after a select every particle
+ * is a copy of the winner (img[best_path.repeat(n_paths)], :633), so x_t is [1, c, h, w] and model_out [1, 2c, h, w] -- one
+ * model evaluation per step for the caller -- while noise, sample and costs stay per particle ([n, ...]).  x_next (nullable)
+ * receives the winner ONCE, [1, c, h, w].  Results are those of dpsx_search_step_f32 on n copies of the state, bit for bit. */
+int dpsx_search_step_one_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise,
+                             const float *y, int64_t y_n, float *sample, float *costs,
+                             int64_t *best_idx_dev, float *best_val_dev, float *x_next,
+                             int64_t n, int64_t c, int64_t h, int64_t w, const dpsx_coefs *coefs_host,
+                             void *workspace, int64_t workspace_bytes, void *stream);
+
 /* SearchDDPM.resample_update's cost update (gaussian_diffusion.py:556-585):
  *   curr[p] = ||y - A(x_p)||_1^2 / (c*h*w)                                         (:557-563)
  *   net[p]  = curr + prev (MEAN) | min(curr, prev) (MIN, NaN propagates as torch.min) | curr - prev (DIFF) | curr (CURR)

@@ -41,6 +41,8 @@ def _worker(rank, world, port, q):
         # per-step select: everybody ends up with n_local copies of the global champion
         sel = dd.GlobalSelect()(mine_s, mine_p)
         out["select_ok"] = bool(all(torch.equal(sel[i], particles[4]) for i in range(n_local)))
+        one = dd.GlobalSelect()(mine_s, mine_p, n_out=1)          # the single-state search loop asks for ONE copy
+        out["select_one_ok"] = bool(one.shape[0] == 1 and torch.equal(one[0], particles[4]))
         # resampling: identical ids on every rank, states fetched from their owners
         ids = dd.resample_ids(mine_s, 100.0, torch.Generator().manual_seed(77))
         out["ids"] = ids.tolist()
@@ -107,7 +109,7 @@ def test_world_size_2_gloo():
         assert res[r]["gathered"] == [5.0, 2.0, 9.0, 2.0, 1.5, 7.0]
         assert res[r]["best"] == 4 and res[r]["winner_ok"]
         assert res[r]["tie_best"] == 1
-        assert res[r]["select_ok"] and res[r]["fetch_ok"] and res[r]["flat"]
+        assert res[r]["select_ok"] and res[r]["select_one_ok"] and res[r]["fetch_ok"] and res[r]["flat"]
     assert res[0]["ids"] == res[1]["ids"] and len(res[0]["ids"]) == 6
     # same draw as a single process would make from the gathered scores (torch.multinomial, shared seed)
     w = torch.exp(-torch.tensor([5.0, 2.0, 9.0, 2.0, 1.5, 7.0]) / 100.0)

@@ -697,20 +697,28 @@ def test_base_loop_diffstategrad_golden(K, golden, tag):
 
 
 @pytest.mark.parametrize("tag,oname", [("sr4", "sr4"), ("gauss", "gauss")])
-def test_search_ddpm_golden(K, golden, tag, oname):
-    """per-step best-of-N: winner indices bit-exact, costs and final image within 1e-5 / 1e-4"""
+@pytest.mark.parametrize("single", [True, False])
+def test_search_ddpm_golden(K, golden, tag, oname, single):
+    """per-step best-of-N: winner indices bit-exact, costs and final image within 1e-5 / 1e-4 -- with the loop's state
+    held as one particle after the first select (the default) and as N copies (the reference's form)"""
     g = golden("search")
     op, _ = make_product_op(oname, hw=64)
     smp = _sampler("search_ddpm", "20")
+    smp.single_state = single
     model = StandInModel().to(DEV)
-    best = []
-    orig = smp.search_step
+    best, calls = [], {"n": 0, "one": 0}
 
-    def spy(*a, **kw):                     # the select is fused into the scoring launch: read its device-side index
-        r = orig(*a, **kw)
-        best.append(int(smp.last_best))
-        return r
-    smp.search_step = spy
+    def spy_on(name):                      # the select is fused into the scoring launch: read its device-side index
+        orig = getattr(smp, name)
+
+        def spy(*a, **kw):
+            r = orig(*a, **kw)
+            best.append(int(smp.last_best))
+            calls["one" if name == "search_step_one" else "n"] += 1
+            return r
+        setattr(smp, name, spy)
+    spy_on("search_step")
+    spy_on("search_step_one")
     torch.manual_seed(int(g[f"{tag}.rng_seed"]))
     img = smp.p_sample_loop(model=model, x_start=dev(g[f"{tag}.x_start"]), measurement=dev(g[f"{tag}.y"]),
                             measurement_cond_fn=None, record=False, save_root=None, operator=op, trace=True)
@@ -719,6 +727,7 @@ def test_search_ddpm_golden(K, golden, tag, oname):
     assert rel_l2(costs, g[f"{tag}.cost"]) < 1e-5
     assert rel_l2(host(img), g[f"{tag}.final"]) < 1e-4
     assert img.shape == (5, 3, 64, 64) and torch.equal(img[0], img[4])
+    assert calls == ({"n": 1, "one": 19} if single else {"n": 20, "one": 0})
 
 
 def test_ttc_driver_call_returns_bare_tensor(K, golden):
@@ -987,3 +996,26 @@ def test_search_step_fused_equals_separate(K, oracle, name, hw, n, t):
                 assert torch.equal(x_next, ref_sample[int(ref_best)].unsqueeze(0).expand_as(x_next))
             else:
                 assert x_next is None
+
+
+@pytest.mark.parametrize("name,hw,n", [("gauss", 256, 9), ("gauss", 64, 5), ("sr4", 256, 5), ("inpaint", 64, 4), ("motion", 128, 3)])
+@pytest.mark.parametrize("t", [700, 0])
+def test_search_step_one_state_equals_replicated(K, oracle, name, hw, n, t):
+    """dpsx_search_step_one_f32 (one state particle feeds all N proposals, the winner is copied out once) ==
+    dpsx_search_step_f32 on N copies of that state, bit for bit: proposals, costs, winner index, winner"""
+    rng = np.random.RandomState(hw + n + t + 1)
+    mask = (np.random.RandomState(3).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5), mask=mask)
+    _, ck = coefs_of(K, oracle, t)
+    x1 = dev(rng.randn(1, 3, hw, hw).astype(np.float32))
+    mo1 = dev(rng.randn(1, 6, hw, hw).astype(np.float32) * 0.5)
+    z = dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(x1)
+    y = op.forward(dev(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32)), **fkw).detach().contiguous()
+    x_rep, s_rep, c_rep, b_rep, v_rep = handle.search_step(x1.repeat(n, 1, 1, 1), mo1.repeat(n, 1, 1, 1), z, y, ck)
+    w_one, s_one, c_one, b_one, v_one = handle.search_step_one(x1, mo1, z, y, ck)
+    assert torch.equal(s_one, s_rep) and torch.equal(c_one, c_rep)
+    assert int(b_one) == int(b_rep) and torch.equal(v_one, v_rep)
+    assert torch.equal(w_one, x_rep[:1]) and torch.equal(w_one, s_rep[int(b_rep)].unsqueeze(0))
+    w_none = handle.search_step_one(x1, mo1, z, y, ck, want_winner=False)[0]
+    assert w_none is None

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--particles", type=int, default=64)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--unfused", action="store_true", help="S1 and the scoring launch separately (the sequence other operators run)")
+    ap.add_argument("--one", action="store_true",
+                    help="the single-state step (dpsx_search_step_one_f32): one state particle, N proposals, winner copied once")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -37,6 +39,8 @@ def main():
 
     def step(i, x):
         s = ring[i % 2]
+        if args.one:                # x: [1, C, H, W]; the model output of the one state particle
+            return handle.search_step_one(x, s["model_out"][:1], s["noise"], y, ck)[0]
         if not args.unfused:        # what SearchDDPM.search_step runs: dpsx_search_step_f32 + dpsx_replicate_f32
             return handle.search_step(x, s["model_out"], s["noise"], y, ck)[0]
         _, sample = kernels.posterior_fwd(x, s["model_out"], s["noise"], ck, want_x0=False)
@@ -45,7 +49,7 @@ def main():
             return kernels.replicate(sample, best)
         return None
 
-    x = x_t
+    x = x_t[:1].contiguous() if args.one else x_t
     for i in range(3):
         x = step(i, x)
     torch.cuda.synchronize()
@@ -56,6 +60,12 @@ def main():
         b.record()
     torch.cuda.synchronize()
     ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    if args.one:
+        algo = 8 * bench.P_BYTES * n
+        print(f"search step (one state particle) N={n} {args.operator}: avg {ts.mean():.1f} us  min {ts.min():.1f} us  "
+              f"{n / ts.mean() * 1e6:.0f} particle-steps/s  {algo / ts.mean() / 1e3:.0f} GB/s against the replicated "
+              f"form's 8P/particle ({3 * bench.P_BYTES * n / ts.mean() / 1e3:.0f} GB/s on the 3P it moves)")
+        return
     # the launches one by one (each timed alone, back to back with itself)
     s0 = ring[0]
     _, sample = kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck, want_x0=False)

@@ -32,6 +32,8 @@ python3 tools/trace_by_grid.py $OUT/${TAG}_stats > $OUT/${TAG}_bench_kernel_trac
   python3 tools/kbench.py --operator gaussian_blur --sigma 5.0 --only fwd,bwd,upd 2>/dev/null
   echo "== search_ddpm step"
   for op in gaussian_blur super_resolution inpainting; do python3 tools/kbench_search.py --operator $op 2>/dev/null; done
+  echo "== search_ddpm step, the loop's state held as ONE particle (dpsx_search_step_one_f32: what SearchDDPM runs after its first select)"
+  for op in gaussian_blur super_resolution inpainting; do python3 tools/kbench_search.py --operator $op --one 2>/dev/null; done
 } > $OUT/${TAG}_operators_kbench.txt
 python3 bench.py --steps 200 --warmup 20 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1_20steps.json 2>> $OUT/${TAG}_bench_n1.err

@@ -43,6 +43,10 @@ struct ResizeDev {
     const int *ell_w_idx;     // [ell_w][in_w] output column (0 where padded)
     const float *ell_w_w;     // [ell_w][in_w] weight (0 where padded)
     int max_he;               // max H-inverse entries of one adjoint block
+    // a second, finer adjoint blocking for small particle counts (planes x blocks of the first one would not fill the
+    // chip: 192 workgroups at N = 16, 256 x 256): chosen at launch, copied over ti / adj_rows / ablk_* / max_he
+    int ti2, adj_rows2, max_he2;
+    const int *ablk_lo2, *ablk_cnt2;
 };
 
 struct ResizeArgs {
@@ -610,37 +614,43 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
     }
     d.tp = best_tp;
     UP(blo, blk_lo) UP(bcnt, blk_cnt) UP(own, own_lo)
-    // ---- adjoint blocking
-    int best_ti = 0;
-    std::vector<int> alo, acnt;
-    for (int ti = 64; ti >= 1; ti >>= 1) {
-        const int nblk = (d.in_h + ti - 1) / ti;
-        std::vector<int> lo((size_t)nblk), cnt((size_t)nblk);
-        int maxrows = 1;
-        for (int b = 0; b < nblk; ++b) {
-            int mn = d.out_h, mx = -1;
-            for (int i = b * ti; i < std::min(d.in_h, (b + 1) * ti); ++i)
-                for (int e = hp[(size_t)i]; e < hp[(size_t)i + 1]; ++e) {
-                    mn = std::min(mn, hi[(size_t)e]);
-                    mx = std::max(mx, hi[(size_t)e]);
-                }
-            if (mx < mn) { mn = 0; mx = 0; }
-            lo[(size_t)b] = mn;
-            cnt[(size_t)b] = mx - mn + 1;
-            maxrows = std::max(maxrows, mx - mn + 1);
+    // ---- adjoint blocking: the largest ti (<= ti_max) whose staged rows fit the LDS budget
+    auto adj_blocking = [&](int ti_max, int &best_ti, int &rows, int &he, std::vector<int> &alo, std::vector<int> &acnt) {
+        for (int ti = ti_max; ti >= 1; ti >>= 1) {
+            const int nblk = (d.in_h + ti - 1) / ti;
+            std::vector<int> lo((size_t)nblk), cnt((size_t)nblk);
+            int maxrows = 1;
+            for (int b = 0; b < nblk; ++b) {
+                int mn = d.out_h, mx = -1;
+                for (int i = b * ti; i < std::min(d.in_h, (b + 1) * ti); ++i)
+                    for (int e = hp[(size_t)i]; e < hp[(size_t)i + 1]; ++e) {
+                        mn = std::min(mn, hi[(size_t)e]);
+                        mx = std::max(mx, hi[(size_t)e]);
+                    }
+                if (mx < mn) { mn = 0; mx = 0; }
+                lo[(size_t)b] = mn;
+                cnt[(size_t)b] = mx - mn + 1;
+                maxrows = std::max(maxrows, mx - mn + 1);
+            }
+            int max_he = 1;
+            for (int b = 0; b < nblk; ++b)
+                max_he = std::max(max_he, hp[(size_t)std::min(d.in_h, (b + 1) * ti)] - hp[(size_t)(b * ti)]);
+            const size_t lds = ((size_t)(maxrows + ti) * d.out_w + 2 * (size_t)(d.ell_w * d.in_w + max_he) + ti + 8) * 4;
+            if (lds <= kLdsBudget || ti == 1) {
+                best_ti = ti; rows = maxrows; alo = lo; acnt = cnt; he = max_he;
+                return lds <= 150 * 1024;
+            }
         }
-        int max_he = 1;
-        for (int b = 0; b < nblk; ++b)
-            max_he = std::max(max_he, hp[(size_t)std::min(d.in_h, (b + 1) * ti)] - hp[(size_t)(b * ti)]);
-        const size_t lds = ((size_t)(maxrows + ti) * d.out_w + 2 * (size_t)(d.ell_w * d.in_w + max_he) + ti + 8) * 4;
-        if (lds <= kLdsBudget || ti == 1) {
-            best_ti = ti; d.adj_rows = maxrows; alo = lo; acnt = cnt; d.max_he = max_he;
-            if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
-            break;
-        }
+        return false;
+    };
+    std::vector<int> alo, acnt, alo2, acnt2;
+    if (!adj_blocking(64, d.ti, d.adj_rows, d.max_he, alo, acnt) ||
+        !adj_blocking(std::max(1, std::min(16, d.ti / 4)), d.ti2, d.adj_rows2, d.max_he2, alo2, acnt2)) {
+        for (void *p : h->allocs) (void)hipFree(p);
+        delete h;
+        return DPSX_EUNSUPPORTED;
     }
-    d.ti = best_ti;
-    UP(alo, ablk_lo) UP(acnt, ablk_cnt)
+    UP(alo, ablk_lo) UP(acnt, ablk_cnt) UP(alo2, ablk_lo2) UP(acnt2, ablk_cnt2)
 #undef UP
     op->d_w_h = reinterpret_cast<float *>(h);  // opaque owner pointer (see resize_destroy)
     return DPSX_OK;
@@ -704,7 +714,12 @@ static int launch_fwd(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
 template <bool EPI>
 static int launch_adj(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStream_t s)
 {
-    const ResizeDev &d = dev_of(op);
+    ResizeDev d = dev_of(op);
+    // few planes: the coarse blocking would leave most of the 256 CUs without a workgroup (N = 16 at 256 x 256: 192 of
+    // them) -- take the fine one
+    if ((int64_t)a.planes * ((d.in_h + d.ti - 1) / d.ti) < 2 * 256 && d.ti2 < d.ti) {
+        d.ti = d.ti2; d.adj_rows = d.adj_rows2; d.max_he = d.max_he2; d.ablk_lo = d.ablk_lo2; d.ablk_cnt = d.ablk_cnt2;
+    }
     const unsigned grid = (unsigned)(a.planes * ((d.in_h + d.ti - 1) / d.ti));
     const size_t lds = ((size_t)(d.adj_rows + d.ti) * d.out_w + 2 * (size_t)(d.ell_w * d.in_w + d.max_he) + d.ti + 8) * 4;
     if (vec) RZ_LAUNCH((k_resize_adj<EPI, true>), grid, lds, s, a, d);

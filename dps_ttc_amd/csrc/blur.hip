@@ -968,7 +968,9 @@ __device__ __forceinline__ void adj_fused(v2f (&acc)[PRW], const float *s0, cons
     if (g.vh_on) strip_finish<PRS>(acc, vh, sl, py, px, wr0, r0);        // wave-uniform
 }
 
-template <bool EPI, int SWC>
+// PRS: rows per lane of the mirrored-column strips -- 2 (8 column pairs x 8 row groups: a 16-column strip, taps reaching
+// <= 14 columns past the border) or 4 (16 x 4: 32 columns, <= 30); chosen by the host from the kernel's reach
+template <bool EPI, int SWC, int PRS>
 __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, AdjReach reach)
 {
     const int RH = TH + g.t + g.b, RW = TW + g.l + g.r, SW = SWC > 0 ? SWC : RW;
@@ -1002,7 +1004,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, 
     ln.row_lo = -g.t; ln.row_hi = TH + g.b; ln.col_lo = -g.l; ln.col_hi = TW + g.r;
     // at most one mirrored side per axis, strip wide enough: one scan of the table (adj_fused)
     const int hrch = lef ? reach.r : reach.l;
-    const bool fused = !(top && bot) && !(lef && rig) && !((lef || rig) && hrch > 30) && !ABL(4);      // block-uniform
+    const bool fused = !(top && bot) && !(lef && rig) && !((lef || rig) && hrch > (PRS == 2 ? 14 : 30)) && !ABL(4);      // block-uniform
     if (fused) {
         const int py = top ? 1 : (bot ? 2 : 0), px = (lef && reach.r >= 1) ? 1 : ((rig && reach.l >= 1) ? 2 : 0);
         const int cy = py == 2 ? CM : 0, cx = px == 2 ? CM : 0;
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps_adj(BlurArgs a, TapGeom g, 
             f.h_hi[c] = px == 1 ? a.nhlo[c] : a.nrun[c];
             if (!f.h_on) f.h_hi[c] = f.h_lo[c] = 0;
         }
-        adj_fused<SWC, 4>(acc, s0, SW, f, a, py, px, cy, cx, wr0, r0);
+        adj_fused<SWC, PRS>(acc, s0, SW, f, a, py, px, cy, cx, wr0, r0);
     } else
 #pragma unroll 1
     for (int py = 0; py < 3; ++py) {
@@ -1378,11 +1380,19 @@ int64_t blur_adjoint_scratch_bytes(const dpsx_op *op, int64_t planes, int64_t h,
     return ((planes * (h + 2 * r4) * (w + 2 * r4) * 4 + 255) / 256) * 256;
 }
 
+template <bool EPI, int SWC, int PRS>
+static int launch_taps_adj1_kp(const BlurArgs &a, const TapGeom &g, const AdjReach &reach, hipStream_t s)
+{
+    const size_t lds = taps_lds(g, SWC);
+    DPSX_LAUNCH((k_blur_taps_adj<EPI, SWC, PRS>), grid_blocks(a), lds, s, a, g, reach);
+}
+
 template <bool EPI, int SWC>
 static int launch_taps_adj1_k(const BlurArgs &a, const TapGeom &g, const AdjReach &reach, hipStream_t s)
 {
-    const size_t lds = taps_lds(g, SWC);
-    DPSX_LAUNCH((k_blur_taps_adj<EPI, SWC>), grid_blocks(a), lds, s, a, g, reach);
+    // strip width by the taps' horizontal reach (both sides use the same kernel instance)
+    if (std::max(reach.l, reach.r) <= 14) return launch_taps_adj1_kp<EPI, SWC, 2>(a, g, reach, s);
+    return launch_taps_adj1_kp<EPI, SWC, 4>(a, g, reach, s);
 }
 
 // regular geometry: one launch on the image domain (k_blur_taps_adj)

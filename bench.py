@@ -326,11 +326,10 @@ def main():
 
     # ---- per-kernel durations (HIP events on the launch stream), outside the timed region: ONE chain of all N particles,
     # launches back to back with nothing beside them
-    reps = min(args.steps, 50)
-    if nch > 1:
-        for i in range(5):          # the one-chain buffers have not been touched yet
-            x = step(i, x)
-        torch.cuda.synchronize()
+    reps = 50                       # independent of --steps: a short timed region should not mean a noisy launch average
+    for i in range(10):             # (with particle groups the one-chain buffers have not been touched yet)
+        x = step(i, x)
+    torch.cuda.synchronize()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps):
         x = step(args.warmup + args.steps + i, x, evs[i])

@@ -927,11 +927,13 @@ def test_in_launch_reduction_sees_fresh_partials(K, name, hw, n):
 
 
 @pytest.mark.parametrize("hw", [(128, 192), (192, 128), (256, 256), (128, 128)])
-@pytest.mark.parametrize("kind,seed", [("motion", 2), ("motion", 7), ("gauss_taps", 0), ("wide", 0), ("widest", 0), ("onesided", 3)])
+@pytest.mark.parametrize("kind,seed", [("motion", 2), ("motion", 7), ("gauss_taps", 0), ("mid", 1), ("wide", 0), ("widest", 0),
+                                       ("onesided", 3)])
 def test_taps_regular_multi_tile(K, oracle, kind, seed, hw):
     """tap-list operator on regular multi-tile images (loads-first stage; the one-launch adjoint: plain + mirrored-row
     windows, mirrored-column / corner strips in one scan of the run table) for kernels of different reach -- a short
-    path, the 25 x 25 Gaussian as a tap list (reach 12), a kernel that reaches 29 px on every side (16-pair strips), a
+    path and the 25 x 25 Gaussian as a tap list (reach <= 12: 16-column strips), a kernel reaching 20 columns (32-column
+    strips), one that reaches 29 px on every side (beyond the strips once rounded to 32: the multi-pass fallback), a
     65 x 65 kernel that reaches 32 px (beyond the strips: the multi-pass fallback) and a kernel whose taps all lie on one
     side of the centre (empty strip ranges) -- against the oracle, plus <A x, u> = <x, A^T u>"""
     rng = np.random.RandomState(seed + hw[0])
@@ -939,6 +941,12 @@ def test_taps_regular_multi_tile(K, oracle, kind, seed, hw):
         k2 = synthetic_motion_kernel(61, seed)
     elif kind == "gauss_taps":
         k2 = oracle.tables.gaussian_kernel2d(61, 3.0).astype(np.float32)
+    elif kind == "mid":          # reach 18-20 columns: the 32-column strips (4 rows per lane) of the one-scan adjoint
+        k2 = np.zeros((61, 61), dtype=np.float32)
+        idx = np.stack([rng.randint(20, 41, size=36), rng.randint(10, 51, size=36)], axis=1)
+        k2[idx[:, 0], idx[:, 1]] = rng.rand(36).astype(np.float32)
+        k2[30, 10] = k2[30, 50] = 0.2
+        k2 /= k2.sum()
     elif kind == "widest":
         k2 = np.zeros((65, 65), dtype=np.float32)
         idx = rng.randint(0, 65, size=(48, 2))

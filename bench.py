@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
     ap.add_argument("--operator", default="gaussian_blur", choices=sorted(ALGO_P))
+    ap.add_argument("--x0-store", action="store_true",
+                    help="K1 also writes the x0_hat image out.  The `ps` loop reads it nowhere after K1 (the backward half "
+                         "works from the clamp gate), so p_sample_loop -- and this bench -- ask for it only when something "
+                         "consumes it (a progress snapshot, the semantic term); inpainting / phase retrieval always write it")
     ap.add_argument("--chains", type=int, default=2,
                     help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,7 +240,7 @@ def main():
         s = ring[i % len(ring)]
         if timers is not None:
             timers[0].record()
-        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck)
+        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck, want_x0=args.x0_store)
         if timers is not None:
             timers[1].record()
         kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], ck)
@@ -279,7 +283,7 @@ def main():
         s = g["ring"][i % len(ring)]
         if timers is not None:
             timers[0].record()
-        kernels.step_fwd(g["handle"], g["buf"], g["x"], s["model_out"], s["noise"], y, ck)
+        kernels.step_fwd(g["handle"], g["buf"], g["x"], s["model_out"], s["noise"], y, ck, want_x0=args.x0_store)
         if timers is not None:
             timers[1].record()
         kernels.step_bwd(g["handle"], g["buf"], y, spec["scale"], spec["power"], ck)
@@ -413,6 +417,7 @@ def main():
                        "operator": args.operator, "particles_per_gpu": n, "global_particles": total,
                        "image": "3x256x256",
                        "chains_per_gpu": nch,
+                       "x0_hat_store": bool(args.x0_store) or args.operator in ("inpainting", "phase_retrieval"),
                        "parallelism": f"particles sharded x{world}; per GPU {nch} independent particle group(s), one HIP "
                                       f"stream each; champion all-gather at the select"},
             "roofline": roofline,

@@ -167,11 +167,11 @@ __device__ __forceinline__ void load_region(float *s_in, const int SW, const int
                     float *smp = a.sample + (int64_t)plane * hw + o;
                     uint8_t *inp = a.inside_w + (int64_t)plane * hw + o;
                     if constexpr (VEC) {
-                        *reinterpret_cast<float4 *>(x0p) = make_float4(val[0], val[1], val[2], val[3]);
+                        if (a.x0_hat) *reinterpret_cast<float4 *>(x0p) = make_float4(val[0], val[1], val[2], val[3]);
                         *reinterpret_cast<float4 *>(smp) = make_float4(sm[0], sm[1], sm[2], sm[3]);
                         *reinterpret_cast<uchar4 *>(inp) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
                     } else {
-                        *x0p = val[0];
+                        if (a.x0_hat) *x0p = val[0];
                         *smp = sm[0];
                         *inp = ins[0];
                     }
@@ -365,7 +365,7 @@ __device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW
             sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
             sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
             const int64_t o = (int64_t)plane * hw + (unsigned)((h0 + row) * w + w0 + 4 * cu);
-            *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+            if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
             *reinterpret_cast<float4 *>(a.sample + o) = sm;
             *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
             val = x0;

@@ -235,7 +235,7 @@ __device__ __forceinline__ void load_region_fast(float *s, const int h0, const i
                 sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
                 sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
                 const int64_t o = (int64_t)plane * hw + (int64_t)gy * w + gx;
-                *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+                if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;      // launch-uniform: optional output
                 *reinterpret_cast<float4 *>(a.sample + o) = sm;
                 *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
             }
@@ -359,7 +359,7 @@ __device__ __forceinline__ void load_region_reg(float *s, const int h0, const in
             sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
             sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
             const int64_t o = (int64_t)plane * hw + (unsigned)((h0 + row) * w + w0 + 4 * cu);
-            *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
+            if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;          // launch-uniform: optional output
             *reinterpret_cast<float4 *>(a.sample + o) = sm;
             *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
             val = x0;

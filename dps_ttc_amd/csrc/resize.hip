@@ -174,11 +174,11 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
                         for (int e = 0; e < U; ++e) sm[e] = post_sample(xv[bb][e], val[e], vq[bb][e], zq[bb][e], a.k);
                         const int64_t po = (int64_t)plane * ihw + (int64_t)gy * d.in_w + gx;
                         if constexpr (VEC) {
-                            *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                            if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
                             *reinterpret_cast<float4 *>(a.sample + po) = make_float4(sm[0], sm[1], sm[2], sm[3]);
                             *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
                         } else {
-                            a.x0_hat[po] = val[0];
+                            if (a.x0_hat) a.x0_hat[po] = val[0];
                             a.sample[po] = sm[0];
                             a.inside_w[po] = ins[0];
                         }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
                     sm.z = post_sample(xv[bb].z, val[2], vq[bb].z, zq[bb].z, a.k);
                     sm.w = post_sample(xv[bb].w, val[3], vq[bb].w, zq[bb].w, a.k);
                     const int64_t po = (int64_t)plane * ihw + (unsigned)(gy * d.in_w + 4 * cu);
-                    *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                    if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
                     *reinterpret_cast<float4 *>(a.sample + po) = sm;
                     *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
                 }

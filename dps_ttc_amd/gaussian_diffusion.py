@@ -246,7 +246,8 @@ class GaussianDiffusion:
             self._bufs = (handle, kernels.StepBuffers(handle, n, c, h, w, x.device))
         return self._bufs[1]
 
-    def dps_step(self, model, x_prev, idx, measurement, method, cond_kw, handle, noise=None, loop_kw=None):
+    def dps_step(self, model, x_prev, idx, measurement, method, cond_kw, handle, noise=None, loop_kw=None,
+                 want_x0=False):
         """One fused DPS step at loop index idx.  Returns (x_next, norm[N]) -- device tensors that live in the
         sampler's persistent step buffers (valid until the next step; the loops clone what they hand out).
         loop_kw: the keyword arguments the calling loop passes to measurement_cond_fn besides the tensors
@@ -263,10 +264,12 @@ class GaussianDiffusion:
         buf = self._buffers(handle, x_prev)
         xp = kernels.f32c(x_prev.detach(), "x_t")
         y = kernels.f32c(measurement, "measurement")
-        kernels.step_fwd(handle, buf, xp, mo, noise, y, coefs)
         if loop_kw is None:
             loop_kw = {'beta_scale': self.betas[idx], 't': idx / self.num_timesteps}
         spec = method.fused_spec(**loop_kw, **cond_kw)
+        # x0_hat is consumed inside K1 (A(x0_hat), the clamp gate): the image itself is written out only when something
+        # reads it afterwards -- the semantic term's embedder, a progress snapshot (want_x0)
+        kernels.step_fwd(handle, buf, xp, mo, noise, y, coefs, want_x0=want_x0 or "semantic" in spec)
         g_sem, self._step_semantic = None, None
         if "semantic" in spec:            # embedder forward + VJP on x0_hat (torch), between the two HIP halves
             g_sem, self._step_semantic = spec["semantic"](buf.x0_hat)
@@ -301,7 +304,8 @@ class GaussianDiffusion:
                 if self.rng_parity:
                     # the reference's q_sample draw (:224), result unused by ps*
                     self._randn(measurement, self.parity_measurement_stride)
-                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise)
+                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise,
+                                              want_x0=bool(record) and idx % 100 == 0)
                 if self._step_semantic is not None:
                     semantic = self._step_semantic
             else:

@@ -410,16 +410,20 @@ class StepBuffers:
         self.flip = 0
 
 
-def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False):
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, want_x0=True):
     """K1.  finalize_norm=False (the loop's setting): buf.norm is filled by the following step_bwd, whose prologue
     finalises the per-tile partial sums this launch leaves in the workspace.  finalize_norm=True: the launch finishes
     buf.norm itself (each particle's last block re-sums the partials in the same fixed order -- same bits) and
-    step_bwd reads one float per particle; measured at N = 64: K1 +4.8 us, K2 -3.3 us, so the loop does not use it."""
+    step_bwd reads one float per particle; measured at N = 64: K1 +4.8 us, K2 -3.3 us, so the loop does not use it.
+    want_x0=False (blur and resize operators): x0_hat is consumed inside the launch and not written to buf.x0_hat --
+    the `ps` step reads it nowhere afterwards (the backward half works from the clamp gate); other operators ignore
+    the flag."""
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, x_t.device)
     buf.norm_ready = bool(finalize_norm)
+    x0_out = buf.x0_hat if want_x0 or handle.kind not in (_lib.KIND_SEP, _lib.KIND_TAPS, _lib.KIND_RESIZE) else None
     check(lib().dpsx_step_fwd_f32(handle._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0],
-                                  ptr(buf.x0_hat), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid),
+                                  ptr(x0_out), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid),
                                   ptr(buf.norm) if finalize_norm else None,
                                   n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(x_t)),
           "dpsx_step_fwd_f32")

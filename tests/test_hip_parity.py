@@ -1027,3 +1027,31 @@ def test_search_step_one_state_equals_replicated(K, oracle, name, hw, n, t):
     assert torch.equal(w_one, x_rep[:1]) and torch.equal(w_one, s_rep[int(b_rep)].unsqueeze(0))
     w_none = handle.search_step_one(x1, mo1, z, y, ck, want_winner=False)[0]
     assert w_none is None
+
+
+@pytest.mark.parametrize("name", ["gauss", "motion", "sr4"])
+def test_fused_step_without_x0_store(K, oracle, name):
+    """dpsx_step_fwd_f32 with x0_hat == NULL (blur, resize): the x0_hat image is consumed inside the launch and not written;
+    everything downstream -- sample, clamp gate, residual, norm, gradient, x_{t-1} -- is bit for bit the same"""
+    rng = np.random.RandomState(11)
+    hw, n = 128, 3
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5))
+    _, ck = coefs_of(K, oracle, 400)
+    x = dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    mo = dev(rng.randn(n, 6, hw, hw).astype(np.float32) * 0.5)
+    z = dev(rng.randn(n, 3, hw, hw).astype(np.float32))
+    gu = dev(rng.randn(n, 3, hw, hw).astype(np.float32) * 1e-2)
+    handle = op.hip_handle(x)
+    y = op.forward(dev(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32)), **fkw).detach().contiguous()
+    outs = []
+    for want in (True, False):
+        buf = K.StepBuffers(handle, n, 3, hw, hw, DEV)
+        buf.x0_hat.fill_(123.0)
+        K.step_fwd(handle, buf, x, mo, z, y, ck, want_x0=want)
+        K.step_bwd(handle, buf, y, 0.5, 1, ck)
+        xn = K.step_update(buf, gu, ck)
+        outs.append((buf.sample.clone(), buf.inside.clone(), buf.norm.clone(), buf.g_model_out.clone(), xn.clone(),
+                     buf.x0_hat.clone()))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    assert bool((outs[1][5] == 123.0).all()) and not bool((outs[0][5] == 123.0).all())

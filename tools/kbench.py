@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--only", default="fwd,bwd,upd,op,adj,score")
     ap.add_argument("--sigma", type=float, default=3.0, help="gaussian_blur only: another radius bucket")
     ap.add_argument("--norm-in-fwd", action="store_true", help="K1 finishes the norm itself (last block of a particle)")
+    ap.add_argument("--no-x0", action="store_true", help="K1 does not write x0_hat out (blur / resize; the `ps` loop's setting)")
     args = ap.parse_args()
     from dps_ttc_amd import kernels
     from dps_ttc_amd.gaussian_diffusion import create_sampler
@@ -48,7 +49,7 @@ def main():
     u = torch.randn((n,) + tuple(y.shape[1:]), device=dev)
     cases = {
         "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck,
-                                           finalize_norm=args.norm_in_fwd), (7 + rho) * P),
+                                           finalize_norm=args.norm_in_fwd, want_x0=not args.no_x0), (7 + rho) * P),
         # as in the loop: the norm is finalised from the forward half's partials (--norm-in-fwd: by K1's own tail)
         "bwd": (lambda i: (setattr(buf, "norm_ready", args.norm_in_fwd), kernels.step_bwd(handle, buf, y, 0.3, 1, ck)),
                 (4 + rho) * P),

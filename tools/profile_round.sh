@@ -38,6 +38,8 @@ python3 tools/trace_by_grid.py $OUT/${TAG}_stats > $OUT/${TAG}_bench_kernel_trac
 python3 bench.py --steps 200 --warmup 20 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1_20steps.json 2>> $OUT/${TAG}_bench_n1.err
 python3 bench.py --steps 200 --warmup 20 --chains 1 --no-cpu-baseline > $OUT/${TAG}_bench_n1_one_chain.json 2>> $OUT/${TAG}_bench_n1.err
+python3 bench.py --steps 200 --warmup 20 --x0-store --no-cpu-baseline > $OUT/${TAG}_bench_n1_x0_store.json 2>> $OUT/${TAG}_bench_n1.err
+python3 bench.py --steps 200 --warmup 20 --x0-store --chains 1 --no-cpu-baseline > $OUT/${TAG}_bench_n1_one_chain_x0_store.json 2>> $OUT/${TAG}_bench_n1.err
 for op in motion_blur super_resolution inpainting phase_retrieval; do
   python3 bench.py --operator $op --steps 100 --warmup 10 --cpu-steps 2 --cpu-particles 16 > $OUT/${TAG}_bench_${op}.json 2>> $OUT/${TAG}_bench_n1.err
 done

@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--x0-store", action="store_true",
                     help="K1 also writes the x0_hat image out.  The `ps` loop reads it nowhere after K1 (the backward half "
                          "works from the clamp gate), so p_sample_loop -- and this bench -- ask for it only when something "
-                         "consumes it (a progress snapshot, the semantic term); inpainting / phase retrieval always write it")
+                         "consumes it (a progress snapshot, the semantic term); inpainting always writes it (its backward half reads it)")
     ap.add_argument("--chains", type=int, default=2,
                     help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -417,7 +417,7 @@ def main():
                        "operator": args.operator, "particles_per_gpu": n, "global_particles": total,
                        "image": "3x256x256",
                        "chains_per_gpu": nch,
-                       "x0_hat_store": bool(args.x0_store) or args.operator in ("inpainting", "phase_retrieval"),
+                       "x0_hat_store": bool(args.x0_store) or args.operator == "inpainting",
                        "parallelism": f"particles sharded x{world}; per GPU {nch} independent particle group(s), one HIP "
                                       f"stream each; champion all-gather at the select"},
             "roofline": roofline,

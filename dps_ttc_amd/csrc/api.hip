@@ -500,8 +500,11 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
     if (!x_t || !model_out || !y || !sample || !inside || !resid || !coefs_host) return DPSX_EINVAL;
     // x0_hat is an optional OUTPUT where the launch consumes it on the fly (blur, resize): the `ps` loop reads it nowhere
     // after this call (the backward half works from the clamp gate), so a caller that does not need the image saves its
-    // store; inpainting's backward half, the identity and the phase-retrieval paths read it back and need it
-    if (!x0_hat && op && op->kind != OP_SEP && op->kind != OP_TAPS && op->kind != OP_RESIZE) return DPSX_EINVAL;
+    // store (blur, resize, the hand-written spectral phase step); inpainting's backward half, the identity and the
+    // library-FFT phase paths read it back and need it
+    if (!x0_hat && op && op->kind != OP_SEP && op->kind != OP_TAPS && op->kind != OP_RESIZE &&
+        !(op->kind == OP_PHASE && phase_is_spectral(op)))
+        return DPSX_EINVAL;
     if ((coefs_host->add_noise & 1) && !noise) return DPSX_EINVAL;
     if (y_n != 1 && y_n != n) return DPSX_EINVAL;
     if (n == 0) return DPSX_OK;

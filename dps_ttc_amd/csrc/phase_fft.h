@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_pr_rows_fwd(const float *__restrict__ x
         sm.y = dpsx::post_sample(xv[r].y, x0.y, vv[r].y, zv[r].y, k);
         sm.z = dpsx::post_sample(xv[r].z, x0.z, vv[r].z, zv[r].z, k);
         sm.w = dpsx::post_sample(xv[r].w, x0.w, vv[r].w, zv[r].w, k);
-        *reinterpret_cast<float4 *>(x0o + o) = x0;
+        if (x0o) *reinterpret_cast<float4 *>(x0o + o) = x0;     // launch-uniform: the image is an optional output
         *reinterpret_cast<float4 *>(so + o) = sm;
         *reinterpret_cast<uchar4 *>(ins + o) = make_uchar4(b0, b1, b2, b3);
         // the padded, shifted row: image columns 4 lane .. + 3 sit at v0 .. v0 + 3; columns 128..255 of v are zero

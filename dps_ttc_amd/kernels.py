@@ -8,6 +8,8 @@ import ctypes
 from ctypes import byref, c_int64, c_void_p
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -133,7 +135,10 @@ class OpHandle:
         _cuda_device(device)
         h = c_void_p()
         check(lib().dpsx_op_create_phase(side, pad, max_planes, byref(h)), "dpsx_op_create_phase")
-        return cls(h, device)
+        obj = cls(h, device)
+        # the hand-written spectral step (256 + 2 x 64 = 384 points) consumes x0_hat inside its first pass
+        obj.spectral = (side, pad) == (256, 64) and "DPSX_PHASE_LIBRARY_FFT" not in os.environ
+        return obj
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -421,7 +426,9 @@ def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, 
     n, c, h, w = buf.shape
     ws = handle.workspace(n, c, h, w, x_t.device)
     buf.norm_ready = bool(finalize_norm)
-    x0_out = buf.x0_hat if want_x0 or handle.kind not in (_lib.KIND_SEP, _lib.KIND_TAPS, _lib.KIND_RESIZE) else None
+    optional = handle.kind in (_lib.KIND_SEP, _lib.KIND_TAPS, _lib.KIND_RESIZE) or \
+        (handle.kind == _lib.KIND_PHASE and (h, w) == (256, 256) and getattr(handle, "spectral", False))
+    x0_out = None if optional and not want_x0 else buf.x0_hat
     check(lib().dpsx_step_fwd_f32(handle._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0],
                                   ptr(x0_out), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid),
                                   ptr(buf.norm) if finalize_norm else None,

@@ -147,7 +147,7 @@ int64_t dpsx_step_resid_bytes(const dpsx_op *op, int64_t n, int64_t c, int64_t h
 /* norm != NULL: the launch finishes the per-particle norms itself (each particle's last block re-sums the partials
  * in a fixed order: deterministic, no extra launch).  norm == NULL: they are finalised by dpsx_step_bwd_f32's
  * prologue from the partial sums left in `workspace` (see there).
- * x0_hat == NULL (blur and resize operators only): pred_xstart is consumed inside the launch -- A(x0_hat), the clamp gate --
+ * x0_hat == NULL (blur and resize operators, phase retrieval at the hand-written 384-point geometry): pred_xstart is consumed inside the launch -- A(x0_hat), the clamp gate --
  * and not written out; the `ps` step reads it nowhere afterwards (posterior_mean_variance.py:96-129 returns it to
  * condition_methods.py:33-60, which uses it for the norm only).  The other operators read it back and require it. */
 int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, const float *noise,

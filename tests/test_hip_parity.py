@@ -1029,12 +1029,12 @@ def test_search_step_one_state_equals_replicated(K, oracle, name, hw, n, t):
     assert w_none is None
 
 
-@pytest.mark.parametrize("name", ["gauss", "motion", "sr4"])
+@pytest.mark.parametrize("name", ["gauss", "motion", "sr4", "phase"])
 def test_fused_step_without_x0_store(K, oracle, name):
     """dpsx_step_fwd_f32 with x0_hat == NULL (blur, resize): the x0_hat image is consumed inside the launch and not written;
     everything downstream -- sample, clamp gate, residual, norm, gradient, x_{t-1} -- is bit for bit the same"""
     rng = np.random.RandomState(11)
-    hw, n = 128, 3
+    hw, n = (256, 2) if name == "phase" else (128, 3)      # the hand-written spectral step is the 256 -> 384 geometry
     op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 5))
     _, ck = coefs_of(K, oracle, 400)
     x = dev(rng.randn(n, 3, hw, hw).astype(np.float32))

@@ -74,8 +74,9 @@ def parse():
                     help="K1 also writes the x0_hat image out.  The `ps` loop reads it nowhere after K1 (the backward half "
                          "works from the clamp gate), so p_sample_loop -- and this bench -- ask for it only when something "
                          "consumes it (a progress snapshot, the semantic term); inpainting always writes it (its backward half reads it)")
-    ap.add_argument("--chains", type=int, default=2,
-                    help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N)")
+    ap.add_argument("--chains", type=int, default=0,
+                    help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N; default: 3, "
+                         "2 for phase retrieval, whose launches hold 52 KB of LDS per workgroup and gain nothing from a third)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -261,12 +262,14 @@ def main():
     # bandwidth-bound launch of one group runs beside the arithmetic-bound launch of another (DESIGN.md, section 5:
     # inside one chain the load / compute / store phases of the tile kernels add up).  Per-particle results do not
     # depend on the grouping (tests/test_driver_gpu.py checks it bit for bit).
-    nch = args.chains if args.chains >= 1 and n % max(args.chains, 1) == 0 else 1
+    nch = max(1, min(args.chains if args.chains > 0 else (2 if args.operator == "phase_retrieval" else 3), n))
     if shared_gpu:
         nch = 1         # rank processes time-slicing ONE GPU (gloo rehearsal): several queues per process make it crawl
-    m = n // nch
+    sizes = [n // nch + (1 if j < n % nch else 0) for j in range(nch)]      # groups may differ by one particle
+    starts = [sum(sizes[:j]) for j in range(nch)]
     groups = []
     for j in range(nch):
+        m = sizes[j]
         if nch == 1:
             gop, ghandle, gbuf, gstream = op, handle, buf, torch.cuda.current_stream()
         else:
@@ -274,7 +277,7 @@ def main():
             ghandle = gop.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else gop.hip_handle(x_t)
             gbuf = kernels.StepBuffers(ghandle, m, 3, 256, 256, device)
             gstream = torch.cuda.Stream(device=device)
-        sl = slice(j * m, (j + 1) * m)
+        sl = slice(starts[j], starts[j] + m)
         groups.append({"op": gop, "handle": ghandle, "buf": gbuf, "stream": gstream, "x": x_t[sl],
                        "ring": [{k: v[sl] for k, v in s.items()} for s in ring]})
 

@@ -415,7 +415,14 @@ class StepBuffers:
         self.flip = 0
 
 
-def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, want_x0=True):
+def _stream_arg(stream, t):
+    """stream: None (torch's current stream on t's device -- a 4.5 us lookup per launch) or a torch.cuda.Stream, whose
+    raw handle a caller that drives several particle groups passes explicitly instead of entering a stream context
+    (another 8 us per group and step: bench.py's three groups cost the host 96 us per step that way, 35 this way)."""
+    return stream_of(t) if stream is None else ctypes.c_void_p(stream.cuda_stream)
+
+
+def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, want_x0=True, stream=None):
     """K1.  finalize_norm=False (the loop's setting): buf.norm is filled by the following step_bwd, whose prologue
     finalises the per-tile partial sums this launch leaves in the workspace.  finalize_norm=True: the launch finishes
     buf.norm itself (each particle's last block re-sums the partials in the same fixed order -- same bits) and
@@ -432,11 +439,11 @@ def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, 
     check(lib().dpsx_step_fwd_f32(handle._h, ptr(x_t), ptr(model_out), ptr(noise), ptr(y), y.shape[0],
                                   ptr(x0_out), ptr(buf.sample), ptr(buf.inside), ptr(buf.resid),
                                   ptr(buf.norm) if finalize_norm else None,
-                                  n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(x_t)),
+                                  n, c, h, w, byref(coefs), ptr(ws), ws.numel(), _stream_arg(stream, x_t)),
           "dpsx_step_fwd_f32")
 
 
-def step_bwd(handle, buf, y, scale, power, coefs, g_x0_extra=None):
+def step_bwd(handle, buf, y, scale, power, coefs, g_x0_extra=None, stream=None):
     """K2.  g_x0_extra: optional [N, C, H, W] cotangent on x0_hat of a further loss term (the semantic-guidance
     term's VJP through the embedder), added to coef * A^T r before the clamp gate."""
     n, c, h, w = buf.shape
@@ -450,15 +457,15 @@ def step_bwd(handle, buf, y, scale, power, coefs, g_x0_extra=None):
                                         ptr(buf.inside), ptr(buf.x0_hat),
                                         ptr(y), y.shape[0], float(scale), int(power), ptr(g_x0_extra),
                                         ptr(buf.g_model_out),
-                                        n, c, h, w, byref(coefs), ptr(ws), ws.numel(), stream_of(buf.x0_hat)),
+                                        n, c, h, w, byref(coefs), ptr(ws), ws.numel(), _stream_arg(stream, buf.x0_hat)),
           "dpsx_step_bwd_extra_f32")
     buf.norm_ready = True
 
 
-def step_update(buf, g_unet, coefs):
+def step_update(buf, g_unet, coefs, stream=None):
     n, c, h, w = buf.shape
     out = buf.x_next[buf.flip]
     buf.flip ^= 1
     check(lib().dpsx_step_update_f32(ptr(buf.sample), ptr(buf.g_model_out), ptr(g_unet), ptr(out), n, c * h * w,
-                                     byref(coefs), stream_of(buf.sample)), "dpsx_step_update_f32")
+                                     byref(coefs), _stream_arg(stream, buf.sample)), "dpsx_step_update_f32")
     return out

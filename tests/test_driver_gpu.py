@@ -170,8 +170,9 @@ def test_bench_self_launch_two_ranks():
     assert rec["value"] > 0 and 0 <= rec["best_of_n_index"] < 8 and "roofline" in rec
 
 
+@pytest.mark.parametrize("explicit", [False, True])
 @pytest.mark.parametrize("operator", ["gaussian_blur", "motion_blur"])
-def test_particle_groups_on_streams_match_one_chain(operator):
+def test_particle_groups_on_streams_match_one_chain(operator, explicit):
     """bench.py's timed loop runs the particles as independent groups on separate HIP streams (own operator handle and
     buffers each): per-particle results must not depend on the grouping -- x_{t-1} and the distances bit for bit."""
     import torch
@@ -195,13 +196,16 @@ def test_particle_groups_on_streams_match_one_chain(operator):
     y = (op.forward(truth.to(dev)).detach() + meas_noise.to(dev)[..., :256, :256]).contiguous()
 
     def run(handle, buf, x, sl, stream):
-        with torch.cuda.stream(stream):
+        # explicit: the stream is handed to the launches (kernels.step_*(stream=), what bench.py does); else a stream context
+        import contextlib
+        kw = {"stream": stream} if explicit else {}
+        with (contextlib.nullcontext() if explicit else torch.cuda.stream(stream)):
             for i in range(steps):
                 ck = smp.step_coefs[999 - 300 * i]
                 s = ring[i % 2]
-                kernels.step_fwd(handle, buf, x, s["model_out"][sl], s["noise"][sl], y, ck)
-                kernels.step_bwd(handle, buf, y, 0.3, 1, ck)
-                x = kernels.step_update(buf, s["g_unet"][sl], ck)
+                kernels.step_fwd(handle, buf, x, s["model_out"][sl], s["noise"][sl], y, ck, want_x0=not explicit, **kw)
+                kernels.step_bwd(handle, buf, y, 0.3, 1, ck, **kw)
+                x = kernels.step_update(buf, s["g_unet"][sl], ck, **kw)
         return x
 
     ref = run(handle, buf, x_t, slice(0, n), torch.cuda.current_stream()).clone()

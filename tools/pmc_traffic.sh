@@ -1,3 +1,7 @@
+#!/bin/bash
+# Only the PMC passes of tools/profile_round.sh: HBM traffic of the three fused launches as the loop issues them (K1 without
+# the x0_hat store), FETCH_SIZE / WRITE_SIZE / the L2 fabric read requests in separate rocprofv3 runs, summarised by
+# tools/parse_pmc.py.   gpurun -- 'bash tools/pmc_traffic.sh'   -> gpurun_out/r02_traffic_summary.json
 set -e -o pipefail
 TAG=r02; OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: starts N rank processes itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): FFHQ-shaped 256x256 RGB,
+Default workload (BASELINE.json configs[2], the configuration the metric is quoted on): FFHQ-shaped 256x256 RGB,
 Gaussian deblur sigma=3.0 (61x61 kernel), N=64 particles per GPU, 'ps' conditioning (scale 0.3).
 One step = the whole non-UNet DPS step over the particle batch -- S1 posterior arithmetic, A(x0_hat) + residual
 + norm, the cotangent back through A^T / clamp to the UNet output, and the update -- three fused HIP launches.
@@ -12,15 +12,28 @@ The UNet is not in the timed region: its output (model_out) and its VJP (g_unet)
 tensors, cycled through a small ring so no step re-reads warm lines; x_t chains from step to step
 as in the real loop, t cycles 999 -> 0 with the real fp32 tables.
 
-Multi-GPU: particles shard across ranks (64 per GPU, weak scaling), no collective inside the step; the timed
-region ends with the global best-of-N select over all ranks' particles (RCCL all-gather of the per-rank
-champions, device-side pick, no host read).
+--workload   what one timed step is (every variant calls the package's own entry points):
+    dps         the DPS step; the timed region ends with ONE global best-of-N select        (configs[2]; default)
+    dps_scores  the DPS step + a per-step all-gather of the per-particle scores over all ranks and the global first-min
+                argmin on the device (dps_ttc_amd.distributed.gather_scores)                 (configs[3]: RCCL score all-gather)
+    search      the search_ddpm step (reference gaussian_diffusion.py:618-633): S1, scoring, per-step global select
+                (distributed.GlobalSelect: champion all-gather), winner replicated            (per-step best-of-N)
+    resample    the ttc_ddim step (DDIM S1) + global multinomial resampling of all ranks' particles every
+                --resample-every steps (distributed.global_resample, reference :685-698)      (configs[4])
+--scaling    weak: --particles is per GPU (default);  strong: --particles is the GLOBAL count, sharded over the ranks
+             (configs[3]: --scaling strong --particles 256 --gpus 8 -> 32 per GPU)
+--semantic   the active semantic-guidance term as a stand-in: a synthetic device-resident cotangent on x0_hat (what the
+             embedder's VJP would return) scaled by the exact anneal scalar of condition_methods.py:155 enters K2 through
+             dpsx_step_bwd_extra_f32 (the face networks themselves are not available offline)
+
+Multi-GPU: particles shard across ranks, no collective inside the DPS step itself; what is exchanged is named above.
 
 Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel from live HIP-event timing, `cpu_baseline`
 is the oracle (a CPU port of the reference path) on a bounded sample of the same workload.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -32,16 +45,42 @@ P_BYTES = 3 * 256 * 256 * 4                    # one fp32 particle image
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 VALU_F32_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 128 FMA lanes x 2.4 GHz)
 
-# algorithmic bytes per particle of the three launches, in units of P.
-#   fwd = S1 6P + S2 (1 + rho)P      bwd = S3 (4 + rho)P      upd = S4 4P      rho = |y| / |x|
-# phase retrieval stores the complex cotangent instead of r: S2 = 5.5P, S3 = 8.5P.
-ALGO_P = {
-    "gaussian_blur": {"fwd": 8.0, "bwd": 5.0, "upd": 4.0},
-    "motion_blur": {"fwd": 8.0, "bwd": 5.0, "upd": 4.0},
-    "super_resolution": {"fwd": 7.0625, "bwd": 4.0625, "upd": 4.0},
-    "inpainting": {"fwd": 7.0, "bwd": 4.0, "upd": 4.0},
-    "phase_retrieval": {"fwd": 11.5, "bwd": 8.5, "upd": 4.0},
-}
+OPERATORS = ("gaussian_blur", "motion_blur", "super_resolution", "inpainting", "phase_retrieval")
+# rho = |y| / |x| of each operator
+RHO = {"gaussian_blur": 1.0, "motion_blur": 1.0, "super_resolution": 1.0 / 16.0, "inpainting": 0.0, "phase_retrieval": 2.25}
+
+
+def algo_p(operator, x0_store=True, workload="dps", semantic=False):
+    """Bytes per particle of each launch, in units of P -- the ONE table bench.py and tools/kbench.py price with.
+
+    "survey":   SURVEY.md 8d's compulsory traffic of the reference algorithm at the boundaries the UNet forces:
+                fwd = S1 6P + S2 (1 + rho)P, bwd = S3 (4 + rho)P, upd = S4 4P; inpainting recomputes r (rho -> 0);
+                phase retrieval stores the complex cotangent instead of r (S2 = 5.5P, S3 = 8.5P).
+    "algorithmic": the same table for the configuration actually launched -- without the x0_hat store (the `ps` step
+                reads the image nowhere after K1) the forward half has no x0_hat write and the backward half no x0_hat
+                read (it works from the clamp gate): fwd - 1P, bwd - 1P.  `roofline.achieved` is priced on this.
+    The bytes the launches are DESIGNED to move are smaller still (the zero variance half of g_model_out and grad_x_direct
+    are never written: DESIGN.md section 2); what they really move is the PMC figure (`traffic`, profiles/traffic.json)."""
+    rho = RHO[operator]
+    if operator == "phase_retrieval":
+        survey = {"fwd": 11.5, "bwd": 8.5, "upd": 4.0}
+    else:
+        survey = {"fwd": 7.0 + rho, "bwd": 4.0 + rho, "upd": 4.0}
+    algo = dict(survey)
+    droppable = operator != "inpainting"          # inpainting's backward half reads x0_hat back (r is recomputed)
+    if not x0_store and droppable:
+        algo["fwd"] -= 1.0
+        algo["bwd"] -= 1.0
+    if semantic:                                   # one more image-sized read in K2 (the extra cotangent)
+        algo["bwd"] += 1.0
+        survey["bwd"] += 1.0
+    if workload == "search":
+        # reference :618-633 -- S1 6P (5P without the x0_hat store) + score 1P + winner gather 1P (+1P written)
+        survey = {"s1": 6.0, "score": 1.0, "select": 1.0}
+        algo = {"s1": 5.0, "score": 1.0, "select": 1.0}
+    return {"survey": survey, "algorithmic": algo}
+
+
 KERNELS = {
     "gaussian_blur": {"fwd": "S1 + A(x0_hat) + residual + norm partials (k_blur_sep_fwd<3,POST,RESID>)",
                       "bwd": "A^T + clamp gate + -b*coef (k_blur_sep_adj<3,EPI>)"},
@@ -54,6 +93,8 @@ KERNELS = {
     "phase_retrieval": {"fwd": "S1 + row FFTs, column FFT + modulus residual + inverse columns (k_pr_rows_fwd + k_pr_cols)",
                         "bwd": "inverse row FFTs + crop + clamp gate + -b*coef (k_pr_rows_inv)"},
 }
+SEARCH_KERNELS = {"s1": "S1 without the x0_hat store (k_posterior_fwd)", "score": "scoring launch: A(sample), residual, per-tile sums",
+                  "select": "costs + torch.argmin-order select + winner replication (k_finalize_select + k_gather)"}
 WORKLOADS = {
     "gaussian_blur": "Gaussian deblur (sigma=3.0, k=61)",
     "motion_blur": "motion deblur (synthetic 61x61 path kernel, intensity 0.5)",
@@ -63,24 +104,29 @@ WORKLOADS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
-    ap.add_argument("--operator", default="gaussian_blur", choices=sorted(ALGO_P))
+    ap.add_argument("--particles", type=int, default=64, help="particles per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--operator", default="gaussian_blur", choices=sorted(OPERATORS))
+    ap.add_argument("--workload", default="dps", choices=["dps", "dps_scores", "search", "resample"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--semantic", action="store_true", help="stand-in semantic-guidance cotangent through dpsx_step_bwd_extra_f32")
+    ap.add_argument("--resample-every", type=int, default=10)
     ap.add_argument("--x0-store", action="store_true",
                     help="K1 also writes the x0_hat image out.  The `ps` loop reads it nowhere after K1 (the backward half "
                          "works from the clamp gate), so p_sample_loop -- and this bench -- ask for it only when something "
                          "consumes it (a progress snapshot, the semantic term); inpainting always writes it (its backward half reads it)")
     ap.add_argument("--chains", type=int, default=0,
-                    help="independent particle groups per GPU, each on its own HIP stream (1 = one chain of N; default: 3, "
-                         "2 for phase retrieval, whose launches hold 52 KB of LDS per workgroup and gain nothing from a third)")
+                    help="independent particle groups per GPU, each on its own HIP stream (kernels.ParticleGroups = "
+                         "sampler.particle_groups; 1 = one chain of N; default: 3, 2 for phase retrieval, whose launches hold "
+                         "52 KB of LDS per workgroup; workloads with a per-step exchange run one chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=5)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------- self-launch
@@ -135,7 +181,7 @@ def launch_ranks(n):
 
 
 # ---------------------------------------------------------------------------------------------- workload
-def synth_inputs(n, ring, device, seed):
+def synth_inputs(n, ring, device, seed, semantic=False):
     """torch.manual_seed(1234) on the CPU, then copied to HBM."""
     import torch
     g = torch.Generator().manual_seed(seed)
@@ -150,6 +196,9 @@ def synth_inputs(n, ring, device, seed):
                      "g_unet": (torch.randn(shape, generator=g) * 1e-2).to(device)})
     truth = torch.rand((1, 3, 256, 256), generator=g) * 2 - 1
     meas_noise = torch.randn((1, 3, 384, 384), generator=g) * 0.05
+    if semantic:        # what the embedder's VJP would hand back: a unit-scale cotangent on x0_hat (scaled per step below)
+        for s in sets:
+            s["g_sem"] = (torch.randn(shape, generator=g) * 1e-3).to(device)
     return x_t.to(device), sets, truth, meas_noise
 
 
@@ -184,6 +233,19 @@ def cpu_model():
     return "unknown"
 
 
+def semantic_scale(sem_guid_scale, anneal_factor, t):
+    """condition_methods.py:155 (the anneal scalar of the semantic term), exact"""
+    return sem_guid_scale * (1 + (anneal_factor - 1) / (1 + math.exp(-10 * (0.3 - t))))
+
+
+def load_traffic(operator):
+    """PMC HBM bytes per launch at N = 64 (profiles/traffic.json: tools/pmc_traffic.sh), or {}"""
+    try:
+        return dict(json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(operator, {}))
+    except Exception:
+        return {}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -196,10 +258,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must match")
 
-    # one hardware queue per HIP stream: with the runtime's default of 4 the particle groups' streams, the null stream
-    # and RCCL's can end up sharing queues (seen once as a 2.4x slower step with three groups); must be set before the
-    # HIP runtime initialises
+    # Both are read when the HIP / HSA runtime initialises, i.e. at the first GPU call below -- set them before anything
+    # touches the device.  One hardware queue per HIP stream: with the runtime's default of 4 the particle groups'
+    # streams, the null stream and RCCL's can end up sharing queues (seen once as a 2.4x slower step with three groups).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -208,7 +271,6 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("DPSX_BENCH_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" only to rehearse on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -221,30 +283,61 @@ def main():
     from dps_ttc_amd.gaussian_diffusion import create_sampler
     from dps_ttc_amd.measurements import get_noise
 
-    n = args.particles
+    # ---- particles of this rank
+    if args.scaling == "strong":
+        counts = dd.shard_counts(args.particles, world)           # contiguous blocks, rank-major (distributed.shard_range)
+        if min(counts) < 1:
+            raise SystemExit(f"--scaling strong: {args.particles} particles do not cover {world} ranks")
+    else:
+        counts = [args.particles] * world
+    n, total = counts[rank], sum(counts)
+    if args.workload == "resample" and len(set(counts)) != 1:
+        raise SystemExit("--workload resample needs equal shards (distributed.resample_particles)")
+
+    wl = args.workload
+    semantic = bool(args.semantic) and wl != "search"
     op, fkw = build_operator(args.operator, device)
     cm = get_conditioning_method("ps", op, get_noise("gaussian", sigma=0.05), scale=0.3)
-    smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
-                         model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
-                         rescale_timesteps=True, timestep_respacing="")
-    x_t, ring, truth, meas_noise = synth_inputs(n, 3, device, 1234 + rank)
+    smp = create_sampler(sampler={"search": "search_ddpm", "resample": "ttc_ddim"}.get(wl, "ddpm"), steps=1000,
+                         noise_schedule="linear", model_mean_type="epsilon", model_var_type="learned_range",
+                         dynamic_threshold=False, clip_denoised=True, rescale_timesteps=True, timestep_respacing="")
+    x_t, ring, truth, meas_noise = synth_inputs(n, 3, device, 1234 + rank, semantic=semantic)
     yy = op.forward(truth.to(device), **fkw).detach()
     y = (yy + meas_noise.to(device)[..., :yy.shape[-2], :yy.shape[-1]]).contiguous()
-    handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
+    mask = fkw.get("mask")
+    handle = op.hip_handle_for(mask) if args.operator == "inpainting" else op.hip_handle(x_t)
     buf = kernels.StepBuffers(handle, n, 3, 256, 256, device)
     spec = cm.fused_spec()
-    counts = [n] * world
+    want_x0 = bool(args.x0_store) or semantic          # the embedder reads x0_hat (p_sample_loop asks for it then, too)
+    if wl == "search":
+        smp.global_select = dd.GlobalSelect() if world > 1 else None
+    res_gen = torch.Generator().manual_seed(0)         # same stream on every rank (distributed.global_resample)
+
+    def coefs_at(i):
+        return smp.sample_coefs(999 - (i % 1000))       # DDPM record; ttc_ddim: the DDIM record
+
+    def sem_cotangent(i, s):
+        """the stand-in semantic cotangent of step i: g_sem scaled by the exact anneal scalar (a [1]-sized host float)"""
+        if not semantic:
+            return None
+        return s["g_sem"], semantic_scale(0.3, 10.0, (999 - (i % 1000)) / 1000.0)
+
+    # ---- one chain of all N particles on torch's current stream (the product loop's default schedule)
+    sem_buf = torch.empty_like(x_t) if semantic else None
 
     def step(i, x, timers=None):
-        t = 999 - (i % 1000)
-        ck = smp.step_coefs[t]
+        ck = coefs_at(i)
         s = ring[i % len(ring)]
+        g_sem = None
+        if semantic:        # [the embedder's forward + VJP on buf.x0_hat would run between K1 and K2: torch, not this path's work]
+            g, sc = sem_cotangent(i, s)
+            g_sem = torch.mul(g, sc, out=sem_buf)
         if timers is not None:
             timers[0].record()
-        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck, want_x0=args.x0_store)
+        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck, want_x0=want_x0)
         if timers is not None:
             timers[1].record()
-        kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], ck)
+        kernels.step_bwd(handle, buf, y, spec["scale"], spec["power"], ck, g_x0_extra=g_sem)
         if timers is not None:
             timers[2].record()
         out = kernels.step_update(buf, s["g_unet"], ck)
@@ -257,103 +350,149 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the timed loop runs the N particles as `chains` independent groups, each with its own operator handle and
-    # buffers on its own HIP stream: the three launches of a step are dependent, the groups are not, so the
-    # bandwidth-bound launch of one group runs beside the arithmetic-bound launch of another (DESIGN.md, section 5:
-    # inside one chain the load / compute / store phases of the tile kernels add up).  Per-particle results do not
-    # depend on the grouping (tests/test_driver_gpu.py checks it bit for bit).
-    nch = max(1, min(args.chains if args.chains > 0 else (2 if args.operator == "phase_retrieval" else 3), n))
-    if shared_gpu:
+    # ---- particle groups on streams: kernels.ParticleGroups, the object sampler.particle_groups / the driver's
+    # --particle_groups run the fused loop with.  Per-particle results do not depend on the grouping
+    # (tests/test_driver_gpu.py checks it bit for bit).  Workloads with an exchange every step run one chain.
+    default_chains = 1 if wl != "dps" or semantic else (2 if args.operator == "phase_retrieval" else 3)
+    nch = max(1, min(args.chains if args.chains > 0 else default_chains, n))
+    if shared_gpu or wl in ("search", "resample", "dps_scores"):
         nch = 1         # rank processes time-slicing ONE GPU (gloo rehearsal): several queues per process make it crawl
-    sizes = [n // nch + (1 if j < n % nch else 0) for j in range(nch)]      # groups may differ by one particle
-    starts = [sum(sizes[:j]) for j in range(nch)]
-    groups = []
-    for j in range(nch):
-        m = sizes[j]
-        if nch == 1:
-            gop, ghandle, gbuf, gstream = op, handle, buf, torch.cuda.current_stream()
-        else:
-            gop, _ = build_operator(args.operator, device)
-            ghandle = gop.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else gop.hip_handle(x_t)
-            gbuf = kernels.StepBuffers(ghandle, m, 3, 256, 256, device)
-            gstream = torch.cuda.Stream(device=device)
-        sl = slice(starts[j], starts[j] + m)
-        groups.append({"op": gop, "handle": ghandle, "buf": gbuf, "stream": gstream, "x": x_t[sl],
-                       "ring": [{k: v[sl] for k, v in s.items()} for s in ring]})
+    pg = None
+    if nch > 1:
+        pg = kernels.ParticleGroups(op, n, 3, 256, 256, device, nch, mask=mask, like=x_t, record_streams=False)
+    state = {"x": x_t, "gx": [x_t[sl] for sl in pg.slices] if pg else None}
 
-    def group_step(g, i, timers=None):
-        # the group's stream is passed to the launches explicitly: no stream context to enter, no current-stream lookup
-        # (tools/host_cost.py: 96 -> 35 us of host time per step for three groups)
-        ck = smp.step_coefs[999 - (i % 1000)]
-        s = g["ring"][i % len(ring)]
-        st = g["stream"]
-        if timers is not None:
-            timers[0].record(st)
-        kernels.step_fwd(g["handle"], g["buf"], g["x"], s["model_out"], s["noise"], y, ck, want_x0=args.x0_store, stream=st)
-        if timers is not None:
-            timers[1].record(st)
-        kernels.step_bwd(g["handle"], g["buf"], y, spec["scale"], spec["power"], ck, stream=st)
-        if timers is not None:
-            timers[2].record(st)
-        g["x"] = kernels.step_update(g["buf"], s["g_unet"], ck, stream=st)
-        if timers is not None:
-            timers[3].record(st)
-
-    def run_steps(first, count, timers=None):
+    def grouped_steps(first, count, timers=None):
         for i in range(count):
-            for j, g in enumerate(groups):
-                group_step(g, first + i, timers[i] if timers is not None and j == 0 else None)
+            ck = coefs_at(first + i)
+            s = ring[(first + i) % len(ring)]
+            for j in range(len(pg)):
+                tm = timers[i] if timers is not None and j == 0 else None
+                st = pg.streams[j]
+                if tm is not None:
+                    tm[0].record(st)
+                pg.step_fwd(j, state["gx"][j], s["model_out"], s["noise"], y, ck, want_x0=want_x0)
+                if tm is not None:
+                    tm[1].record(st)
+                pg.step_bwd(j, y, spec["scale"], spec["power"], ck)
+                if tm is not None:
+                    tm[2].record(st)
+                state["gx"][j] = pg.step_update(j, s["g_unet"], ck)
+                if tm is not None:
+                    tm[3].record(st)
 
-    def join_groups():
-        cur = torch.cuda.current_stream()
-        for g in groups:
-            cur.wait_stream(g["stream"])
-        if nch == 1:
-            return groups[0]["buf"].norm, groups[0]["x"]
-        return torch.cat([g["buf"].norm for g in groups]), torch.cat([g["x"] for g in groups])
+    def chain_steps(first, count):
+        x = state["x"]
+        for i in range(count):
+            k = first + i
+            if wl == "search":
+                # SearchDDPM.search_step without the model call: dpsx_search_step_f32 (+ GlobalSelect across ranks)
+                s = ring[k % len(ring)]
+                local_only = smp.global_select is None
+                x_next, sample, costs, best, _ = handle.search_step(x, s["model_out"], s["noise"], y, coefs_at(k),
+                                                                    replicate=local_only)
+                x = x_next if local_only else smp.global_select(costs, sample)
+                continue
+            x = step(k, x)
+            if wl == "dps_scores":
+                # per-step score all-gather (RCCL) + the global first-min argmin, all on the device
+                state["best"] = dd.first_argmin(dd.gather_scores(buf.norm, counts))
+            elif wl == "resample" and k % args.resample_every == 0:
+                # TTC_DDIM._resample over the sharded particle set: scores all-gathered, identical host draw, states fetched
+                x, _, _ = dd.global_resample(x, buf.norm, 100.0, res_gen)
+        state["x"] = x
 
-    for g in groups:
-        g["stream"].wait_stream(torch.cuda.current_stream())
+    def run_steps(first, count):
+        if pg is not None:
+            grouped_steps(first, count)
+        else:
+            chain_steps(first, count)
+
+    def closing_select():
+        """final best-of-N over all ranks' particles (best_of_n_simple.py:32-40 on the device, no host read)"""
+        if pg is not None:
+            pg.join()
+            return dd.global_best_of_n_device(pg.full.norm, pg.x_next(), counts)
+        if wl == "search":          # every particle is already the global winner
+            return state["x"][:1], torch.zeros((), dtype=torch.int64, device=device)
+        return dd.global_best_of_n_device(buf.norm, state["x"], counts)
+
+    def timed(first, count):
+        barrier()
+        if pg is not None:
+            pg.fork()
+        t0 = time.perf_counter()
+        run_steps(first, count)
+        winner, best_dev = closing_select()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, int(best_dev)
+
+    if pg is not None:
+        pg.fork()
     run_steps(0, args.warmup)
-    norm_all, x_all = join_groups()
-    dd.global_best_of_n_device(norm_all.clone(), x_all, counts)        # warm the select (and the collectives) too
-    barrier()
-    for g in groups:
-        g["stream"].wait_stream(torch.cuda.current_stream())
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    norm_all, x_all = join_groups()
-    winner, best_dev = dd.global_best_of_n_device(norm_all, x_all, counts)   # final best-of-N over all ranks' particles
-    barrier()
-    elapsed = time.perf_counter() - t0
-    best = int(best_dev)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    x = x_t
+    closing_select()                                   # warm the select (and the collectives) too
+    elapsed, best = timed(args.warmup, args.steps)
+
+    # ---- the same steps as ONE chain of all N particles (the schedule of sampler.particle_groups = 1), timed the same
+    # way, so that the line carries both figures
+    one_chain_s = None
+    if pg is not None and wl == "dps":
+        saved, pg_saved = dict(state), pg
+        pg = None
+        state["x"] = x_t
+        run_steps(0, max(args.warmup, 5))
+        one_chain_s, _ = timed(args.warmup, args.steps)
+        pg = pg_saved
+        state.update(saved)
+    elif pg is None:
+        one_chain_s = elapsed
 
     # ---- per-kernel durations (HIP events on the launch stream), outside the timed region: ONE chain of all N particles,
     # launches back to back with nothing beside them
     reps = 50                       # independent of --steps: a short timed region should not mean a noisy launch average
-    for i in range(10):             # (with particle groups the one-chain buffers have not been touched yet)
-        x = step(i, x)
-    torch.cuda.synchronize()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-    for i in range(reps):
-        x = step(args.warmup + args.steps + i, x, evs[i])
-    torch.cuda.synchronize()
-    dur = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) * 1e-3
-           for j, k in enumerate(("fwd", "bwd", "upd"))}
+    x = x_t
+    if wl == "search":
+        s0 = ring[0]
+        ck0 = coefs_at(0)
+        _, sample0 = kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck0, want_x0=False)
+        _, best0, _ = handle.score_argmin(sample0, y)
+        parts = {"s1": lambda: kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck0, want_x0=False),
+                 "score": lambda: handle.score(sample0, y),
+                 "select": lambda: kernels.replicate(sample0, best0)}
+        dur = {}
+        for name, fn in parts.items():
+            for _ in range(5):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a_, b_ in ev:
+                a_.record()
+                fn()
+                b_.record()
+            torch.cuda.synchronize()
+            dur[name] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev])) * 1e-3
+    else:
+        for i in range(10):             # (with particle groups the one-chain buffers have not been touched yet)
+            x = step(i, x)
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+        for i in range(reps):
+            x = step(args.warmup + args.steps + i, x, evs[i])
+        torch.cuda.synchronize()
+        dur = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in evs])) * 1e-3
+               for j, k in enumerate(("fwd", "bwd", "upd"))}
     # ... and the same launches as the timed loop runs them: group 0's (N / chains particles) on its own stream while the
     # other groups' launches run beside them (longer per launch, shorter per step)
     dur_grouped = None
-    if nch > 1:
-        for g in groups:
-            g["stream"].wait_stream(torch.cuda.current_stream())
+    if pg is not None:
+        pg.fork()
         gev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-        run_steps(args.warmup + args.steps, reps, gev)
-        join_groups()
+        grouped_steps(args.warmup + args.steps, reps, gev)
+        pg.join()
         torch.cuda.synchronize()
         dur_grouped = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in gev])) * 1e3
                        for j, k in enumerate(("fwd", "bwd", "upd"))}
@@ -376,32 +515,63 @@ def main():
         del src, dst
 
     if rank == 0:
-        total = n * world
+        x0_stored = want_x0 or args.operator == "inpainting"
+        table = algo_p(args.operator, x0_store=x0_stored, workload=wl, semantic=semantic)
+        algo = {k: v * P_BYTES for k, v in table["algorithmic"].items()}
+        survey_step_p = sum(table["survey"].values())
+        algo_step_p = sum(table["algorithmic"].values())
         value = total * args.steps / elapsed
-        algo = {k: v * P_BYTES for k, v in ALGO_P[args.operator].items()}
-        step_p = sum(ALGO_P[args.operator].values())
+        step_s = elapsed / args.steps
         dom = max(dur, key=dur.get)
-        names = dict(KERNELS[args.operator], upd="x_{t-1} = sample - (a g_pre + g_unet) (k_step_update)")
+        names = dict(SEARCH_KERNELS) if wl == "search" else \
+            dict(KERNELS[args.operator], upd="x_{t-1} = sample - (a g_pre + g_unet) (k_step_update)")
         achieved = algo[dom] * n / dur[dom] / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.operator, {}).get(dom)
-            except Exception:
-                traffic = None
+        # PMC traffic (HBM bytes per launch at N = 64, collected with the x0_hat store off): scaled to this run's N;
+        # valid for the plain `ps` step only
+        pmc_ok = wl != "search" and not semantic and (not x0_stored or args.operator == "inpainting")
+        traffic_tbl = load_traffic(args.operator) if pmc_ok else {}
+        moved = {k: (traffic_tbl[k] * n / 64.0 if k in traffic_tbl else None) for k in dur}
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": moved.get(dom),
                     "algorithmic_bytes_per_launch": algo[dom] * n,
+                    "bytes_priced": "SURVEY 8d compulsory traffic of the configuration launched (x0_hat store "
+                                    + ("on" if x0_stored else "off: fwd and bwd 1P less than the survey table") + ")",
                     "avg_launch_ms": dur[dom] * 1e3,
                     "all_launches_ms": {k: v * 1e3 for k, v in dur.items()},
                     "launch_timing": "one chain of all N particles, launches back to back, HIP events on the launch "
                                      "stream, outside the timed region",
+                    "per_launch": {k: {"algorithmic_bytes": algo[k] * n, "moved_bytes": moved[k],
+                                       "algorithmic_GBps": algo[k] * n / dur[k] / 1e9,
+                                       "moved_GBps": (moved[k] / dur[k] / 1e9) if moved[k] else None,
+                                       "frac_moved": (moved[k] / dur[k] / 1e9 / HBM_PEAK_GBS) if moved[k] else None}
+                                   for k in dur},
                     "grouped_launches_us": dur_grouped,
-                    "step_algorithmic_bytes_per_particle": step_p * P_BYTES,
-                    "step_frac_of_hbm_roofline": (step_p * P_BYTES * n / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
-                    "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs}
-        if args.operator == "motion_blur":
+                    # the whole step: SURVEY 8d's figure (17P for blur -- the reference algorithm's compulsory traffic),
+                    # the figure of the configuration launched, and the bytes the launches really moved (PMC)
+                    "step_survey_bytes_per_particle": survey_step_p * P_BYTES,
+                    "step_algorithmic_bytes_per_particle": algo_step_p * P_BYTES,
+                    "step_frac_of_hbm_roofline": (survey_step_p * P_BYTES * n / step_s) / 1e9 / HBM_PEAK_GBS,
+                    "step_frac_algorithmic": (algo_step_p * P_BYTES * n / step_s) / 1e9 / HBM_PEAK_GBS,
+                    "copy_ceiling": copy_gbs}
+        if one_chain_s is not None:
+            oc = one_chain_s / args.steps
+            roofline["one_chain_ms_per_step"] = oc * 1e3
+            roofline["one_chain_value"] = total * args.steps / one_chain_s
+            roofline["one_chain_step_frac_of_hbm_roofline"] = (survey_step_p * P_BYTES * n / oc) / 1e9 / HBM_PEAK_GBS
+        if all(moved.get(k) for k in dur):
+            mv = sum(moved.values())
+            roofline["step_moved_bytes_per_particle"] = mv / n
+            roofline["step_moved_GBps"] = mv / step_s / 1e9
+            roofline["step_frac_moved"] = mv / step_s / 1e9 / HBM_PEAK_GBS
+            roofline["frac_of_copy_ceiling"] = mv / step_s / 1e9 / copy_gbs
+            if one_chain_s is not None:
+                roofline["one_chain_step_frac_moved"] = mv / (one_chain_s / args.steps) / 1e9 / HBM_PEAK_GBS
+            if roofline["frac_of_copy_ceiling"] > 1.0:
+                # concurrent streams can beat a single 1 GiB copy_ (5.0-5.3 TB/s here against the guide's 6.3 TB/s
+                # float4 copy), so a little above 1 is possible; well above it the byte model is wrong
+                sys.stderr.write(f"bench.py: WARNING moved bytes / step time = {roofline['frac_of_copy_ceiling']:.2f} x the "
+                                 "on-box copy ceiling\n")
+        if args.operator == "motion_blur" and wl != "search":
             # SURVEY 8d exception: the tap-list kernels are priced against the fp32 vector peak as well as HBM;
             # the binding limit is the one with the larger fraction
             taps = int((op.get_kernel() != 0).sum())
@@ -412,23 +582,35 @@ def main():
                                 "frac": {k: v / VALU_F32_PEAK_TFLOPS for k, v in valu.items()}}
             hb, vb = roofline["frac"], valu.get(dom, 0.0) / VALU_F32_PEAK_TFLOPS
             roofline["binding"] = "valu" if vb > hb else "hbm"
+        what = {"dps": "'ps' scale 0.3, one global best-of-N select at the end",
+                "dps_scores": "'ps' scale 0.3, per-step all-gather of the particle scores + global argmin",
+                "search": "search_ddpm step: S1, scoring, per-step global select, winner replicated",
+                "resample": f"ttc_ddim step (DDIM S1) with 'ps' scale 0.3, global multinomial resampling every "
+                            f"{args.resample_every} steps"}[wl]
+        exchange = {"dps": "champion all-gather at the closing select (2 floats + 1 particle per rank)",
+                    "dps_scores": "RCCL all-gather of the [N/G] scores every step",
+                    "search": "per step: all-gather of one (min) + one champion particle per rank, device-side pick",
+                    "resample": f"every {args.resample_every} steps: all-gather of scores, identical host multinomial "
+                                f"draw, all-gather of states + HIP gather"}[wl]
         line = {
             "metric": "particles×denoise-steps/sec @256×256 N=64; x0_hat rel-L2 vs ref",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FFHQ-shaped 256x256 {WORKLOADS[args.operator]}, 'ps' scale 0.3, "
-                                   f"best-of-N N={n}/GPU, DDPM t cycling 999->0",
-                       "operator": args.operator, "particles_per_gpu": n, "global_particles": total,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FFHQ-shaped 256x256 {WORKLOADS[args.operator]}, {what}, "
+                                   f"N={total} particles ({'/'.join(str(c) for c in sorted(set(counts)))} per GPU), "
+                                   f"t cycling 999->0" + (", stand-in semantic-guidance cotangent (anneal 10x)" if semantic else ""),
+                       "operator": args.operator, "step": wl, "particles_per_gpu": n, "global_particles": total,
                        "image": "3x256x256",
                        "chains_per_gpu": nch,
-                       "x0_hat_store": bool(args.x0_store) or args.operator == "inpainting",
-                       "parallelism": f"particles sharded x{world}; per GPU {nch} independent particle group(s), one HIP "
-                                      f"stream each; champion all-gather at the select"},
+                       "x0_hat_store": x0_stored,
+                       "semantic_stand_in": semantic,
+                       "parallelism": f"particles sharded x{world} ({args.scaling} scaling); per GPU {nch} independent "
+                                      f"particle group(s) (kernels.ParticleGroups), one HIP stream each; {exchange}"},
             "roofline": roofline,
             "best_of_n_index": best,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl == "dps" and not semantic:
             line["cpu_baseline"], line["x0_hat_rel_l2"] = cpu_baseline(args, op, fkw, smp, ring, x_t, y, handle, device)
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -486,10 +668,11 @@ def cpu_baseline(args, op, fkw, smp, ring, x_t, y, handle, device):
         for a, b in ((buf.x0_hat, outs[i]["x0_hat"]), (xg, outs[i]["x_next"])):
             a = a.cpu().numpy().astype(np.float64)
             worst = max(worst, float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())))
-    return ({"value": nc * steps / dt, "unit": "particle-steps/s", "cores": cores, "cpu": cpu_model(),
-             "kind": "port",
-             "sample": f"{nc} particles x {steps} steps of the same workload (oracle/dps_oracle.c, OpenMP, "
-                       f"zero taps of a blur kernel skipped), {dt:.1f} s"}, worst)
+    base = {"value": nc * steps / dt, "unit": "particle-steps/s", "cores": cores, "cpu": cpu_model(),
+            "kind": "port",
+            "sample": f"{nc} particles x {steps} steps of the same workload (oracle/dps_oracle.c, OpenMP, "
+                      f"zero taps of a blur kernel skipped), {dt:.1f} s"}
+    return base, worst
 
 
 if __name__ == "__main__":

@@ -550,7 +550,13 @@ int dpsx_step_fwd_f32(dpsx_op *op, const float *x_t, const float *model_out, con
         break;
     default: return DPSX_EUNSUPPORTED;
     }
-    if (rc != DPSX_OK) return rc;
+    if (rc != DPSX_OK) {
+        // a launch that failed part-way may leave arrival counters non-zero: clear them behind whatever did run, so that
+        // the handle's next in-launch reduction does not start from a stale count
+        if (tail_done)
+            (void)hipMemsetAsync(op->d_counters, 0, (size_t)(1 + kTailMaxParticles) * sizeof(unsigned), s);
+        return rc;
+    }
     // norm == NULL: the partial sums stay in `workspace` and dpsx_step_bwd_f32 finalises them in its prologue
     return (norm && !tail_done) ? finalize_norm(ws.partials, parts, norm, n, s) : DPSX_OK;
 }

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t);
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t, a.tail.counters != nullptr);
         tail_arrive(a.tail, plane / a.c);
     }
 }

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NT, sep_waves_per_simd(R4, !POST && !RESID)) void k
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t);
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx], t, a.tail.counters != nullptr);
         tail_arrive(a.tail, plane / a.c);
     }
 }

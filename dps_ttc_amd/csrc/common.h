@@ -168,8 +168,8 @@ __device__ __forceinline__ bool argmin_better(const ArgMin &a, const ArgMin &b) 
 // partials in the fixed order of k_finalize_norm (so the value is bit-identical to the stand-alone finalisation and
 // independent of which block came last) and writes the per-particle value; optionally the last particle to finish
 // runs the argmin over all values.  Nothing waits on anything: a block that is not last just leaves.  Counters are
-// zero between launches (the last arriver resets its counter).  One launch at a time per counter array (= per
-// dpsx_op): an operator handle is not re-entrant across streams, as its workspace is not either.
+// zero between launches (the last arriver resets its counter; the host wrapper clears them if a launch fails).  One launch
+// at a time per counter array (= per dpsx_op): an operator handle serves ONE stream at a time, as its workspace does.
 enum { TAIL_L2 = 0,      // value = sqrt(sum of squares)                      ||y - A x||_2
        TAIL_L1SQ = 1 };  // value = (sum of |.|)^2 * l1_scale                 ||y - A x||_1^2 / (C H W)
 enum { POT_NONE = 0, POT_MEAN = 1, POT_MIN = 2, POT_DIFF = 3, POT_CURR = 4 };   // SearchDDPM.resample_update :565-585
@@ -194,18 +194,31 @@ constexpr int kTailMaxParticles = 1 << 16;    // counters allocated per operator
 
 // Visibility across the 8 XCDs (one L2 each) WITHOUT a device-scope release fence: on gfx950 that fence is a write-back
 // of the whole L2 (`buffer_wbl2`), and with megabytes of freshly written x0_hat / sample lines dirty in it, one fence per
-// block cost 535 us per launch (measured, N = 64).  Instead the few words that other blocks must see -- the partial sums,
-// the finished values -- are written with agent-scope atomic stores (write-through past the XCD's L2), the writer waits
-// for their completion (s_waitcnt) before it bumps the counter, and only the LAST block of a particle (N blocks per
-// launch) pays an acquire fence (an L2 invalidate of non-local lines, no write-back) before it reads them back with
-// agent-scope atomic loads.
+// block cost 535 us per launch (measured, N = 64).  The hand-off is instead the write-through form MI355X_MICROARCH.md
+// lists as valid and measured ("Valid forms", first table row): every handed-off word -- the partial sums, the finished
+// values -- is stored `sc1` (agent-scope atomic store: write-through past the XCD's L2) by ONE lane, which drains its
+// stores with an `asm volatile("s_waitcnt vmcnt(0)" ::: "memory")` -- the asm form, because the compiler may drop or move a
+// builtin wait, and its "memory" clobber keeps the store and the counter add in program order -- before ONE agent-scope
+// atomic add signals for the block; the block whose add returned last (N blocks per launch) takes an agent-scope acquire
+// (an L2 invalidate, no write-back) and reads every word back with `sc1` loads (agent-scope atomic loads).
+// Not the C++ memory model's release / acquire pair (there is no release on the writer side by design: it IS the 535 us
+// write-back); it relies on the documented gfx950 behaviour of sc1 stores, which is why this library targets gfx950 only.
+// The default loops do not take this path (the norm is finalised in the backward launch's prologue, the costs by
+// k_finalize_select); it serves `dpsx_step_fwd_f32(norm != NULL)`.
 __device__ __forceinline__ float tail_ld(const float *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tail_publish(float *p, float v)      // a partial sum other blocks will read
+// a partial sum: read by a later launch (plain store: launch boundaries order it) or, with an in-launch tail, by the last
+// block of its particle (write-through store)
+__device__ __forceinline__ void tail_publish(float *p, float v, bool in_launch_reader)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (in_launch_reader) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ void tail_drain_stores()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Called by ALL threads of every block that wrote a partial of `particle`, after the write (block-uniform call site).
@@ -215,7 +228,7 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
     __shared__ __attribute__((aligned(16))) int s_tail[52];     // flag + 16 x (value, index lo, index hi); 16-byte multiple (G17)
     int *s_flag = s_tail;
     if (threadIdx.x == 0) {                                     // the thread that published the partial
-        __builtin_amdgcn_s_waitcnt(0);                          // ... whose write-through store has completed
+        tail_drain_stores();                                    // ... whose write-through store has completed
         const unsigned prev = __hip_atomic_fetch_add(&t.counters[1 + particle], 1u, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)t.blocks_per_particle - 1u;
@@ -246,7 +259,7 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
     if (!t.best_idx) return;                                    // launch-uniform
     __syncthreads();
     if (threadIdx.x == 0) {                                     // the thread that stored out[particle]
-        __builtin_amdgcn_s_waitcnt(0);
+        tail_drain_stores();
         const unsigned prev = __hip_atomic_fetch_add(&t.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)t.n - 1u;
         if (last) __hip_atomic_store(&t.counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -285,34 +298,6 @@ __device__ __forceinline__ void tail_arrive(const Tail &t, int particle)
         }
         *t.best_idx = best.i < 0 ? 0 : best.i;
         if (t.best_val) *t.best_val = best.v;
-    }
-}
-
-// The same arrival for kernels whose waves have different roles: called by ALL 64 lanes of ONE wave, whose lane 0
-// published the partial.  Per-particle value only (no select).
-__device__ __forceinline__ void tail_arrive_wave(const Tail &t, int particle)
-{
-    if (!t.counters) return;
-    int last = 0;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned prev = __hip_atomic_fetch_add(&t.counters[1 + particle], 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-        last = prev == (unsigned)t.blocks_per_particle - 1u;
-        if (last) __hip_atomic_store(&t.counters[1 + particle], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    last = __shfl(last, 0, kWave);
-    if (!last) return;                                          // wave-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double acc = 0.0;
-    const float *pp = t.partials + (int64_t)particle * t.parts;
-    for (int i = threadIdx.x & (kWave - 1); i < t.parts; i += kWave) acc += (double)tail_ld(pp + i);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        const float v = t.mode == TAIL_L1SQ ? (float)(acc * acc * (double)t.l1_scale) : (float)sqrt(acc);
-        if (t.raw_out) t.raw_out[particle] = v;
-        __hip_atomic_store(t.out + particle, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

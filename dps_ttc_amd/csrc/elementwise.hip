@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void k_residual_partials(const float *__r
         }
     }
     const float t = block_sum(acc, scratch);
-    if (threadIdx.x == 0) tail_publish(&partials[p * gridDim.x + q], t);
+    if (threadIdx.x == 0) tail_publish(&partials[p * gridDim.x + q], t, tail.counters != nullptr);
     tail_arrive(tail, (int)p);
 }
 
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const
         acc = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     }
     const float t = block_sum(acc, scratch);
-    if (threadIdx.x == 0) tail_publish(&a.partials[p * gridDim.x + blockIdx.x], t);
+    if (threadIdx.x == 0) tail_publish(&a.partials[p * gridDim.x + blockIdx.x], t, a.tail.counters != nullptr);
     tail_arrive(a.tail, (int)p);
 }
 

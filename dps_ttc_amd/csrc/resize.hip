@@ -225,7 +225,7 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t);
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t, a.tail.counters != nullptr);
         tail_arrive(a.tail, plane / a.c);
     }
 }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
     }
     if constexpr (RESID) {
         const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t);
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t, a.tail.counters != nullptr);
         tail_arrive(a.tail, plane / a.c);
     }
 }

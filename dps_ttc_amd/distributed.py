@@ -210,7 +210,7 @@ def resample_particles(particles_local, ids_global):
         dist.all_gather_into_tensor(pool, particles_local.contiguous())
     mine = ids_global[rank * n_local:(rank + 1) * n_local]
     if pool.is_cuda:
-        return kernels.gather(pool, mine)
+        return kernels.gather(pool, mine, validate=False)       # ids drawn by resample_ids over the gathered set
     return pool[mine]
 
 

@@ -153,9 +153,20 @@ class GaussianDiffusion:
         self._ts_cache = {}
         self._bufs = None
         self._step_semantic = None
+        #: > 1: the fused base loop runs its N particles as this many independent sub-batches, each a whole chain (model
+        #: call, three HIP launches, model VJP) on its own HIP stream with its own operator handle (kernels.ParticleGroups):
+        #: the tile kernels' load / compute / store phases add up inside one chain, side by side they fill each other's gaps.
+        #: Per-particle results do not depend on it (the noise is still drawn for the whole batch, in the same order).
+        self.particle_groups = 1
+        self._pgroups = None
 
     # -- RNG ---------------------------------------------------------------
-    def _randn(self, like, stride=None):
+    def _randn(self, like, stride=None, shape=None):
+        """standard-normal draw shaped like `like` (or `shape` on like's device: no dummy tensor is allocated)"""
+        if shape is not None:
+            if self.rng_parity:
+                return torch.randn(tuple(shape), dtype=torch.float32).to(like.device)
+            return torch.randn(tuple(shape), dtype=torch.float32, device=like.device)
         if self.rng_parity:
             # replay of the reference's host RNG stream (tests): torch's CPU normal_() consumes the
             # generator differently for non-contiguous tensors, so the layout is part of the stream
@@ -281,6 +292,52 @@ class GaussianDiffusion:
         x_next = kernels.step_update(buf, g_unet, coefs)
         return x_next, buf.norm
 
+    def _particle_group_set(self, method, cond_kw, x):
+        """the sampler's kernels.ParticleGroups for this operator / batch shape (built once, reused across trajectories)"""
+        n, c, h, w = x.shape
+        op, mask = method.operator, cond_kw.get('mask', None)
+        key = (id(op), None if mask is None else (mask.data_ptr(), mask._version), (n, c, h, w), str(x.device),
+               int(self.particle_groups))
+        if self._pgroups is None or self._pgroups[0] != key:
+            self._pgroups = (key, kernels.ParticleGroups(op, n, c, h, w, x.device, self.particle_groups, mask=mask, like=x))
+        return self._pgroups[1]
+
+    def dps_step_grouped(self, model, img, idx, measurement, method, cond_kw, pg, noise, loop_kw=None, want_x0=False):
+        """dps_step over kernels.ParticleGroups: every group's whole step -- model call, K1, [semantic term], K2, model VJP,
+        K3 -- is enqueued on the group's own stream; nothing is joined between steps (group j's next step reads only what
+        group j wrote).  img, noise: full-batch tensors.  Returns (x_next [N, C, H, W], norm [N]) -- views of the group
+        set's full-batch buffers, valid on the CALLER's stream only after pg.join()."""
+        coefs = self.sample_coefs(idx)
+        y = kernels.f32c(measurement, "measurement")
+        if loop_kw is None:
+            loop_kw = {'beta_scale': self.betas[idx], 't': idx / self.num_timesteps}
+        spec = method.fused_spec(**loop_kw, **cond_kw)
+        pg.fork()                 # the noise (and, on the first step, x_start) was produced on the caller's stream
+        sems = []
+        for j in range(len(pg)):
+            with torch.cuda.stream(pg.streams[j]):
+                x_prev = img[pg.slices[j]].detach().requires_grad_()
+                with torch.enable_grad():
+                    model_out = self._call_model(model, x_prev, idx)
+                mo = kernels.f32c(model_out.detach(), "model output")
+                if mo.shape[1] != 2 * x_prev.shape[1]:
+                    raise ValueError("the fused DPS step needs a learned-sigma model ([N, 2C, H, W] output)")
+                pg.step_fwd(j, kernels.f32c(x_prev.detach(), "x_t"), mo, noise, y, coefs,
+                            want_x0=want_x0 or "semantic" in spec)
+                g_sem = None
+                if "semantic" in spec:
+                    g_sem, sem = spec["semantic"](pg.bufs[j].x0_hat)
+                    sems.append(sem)
+                pg.step_bwd(j, y, spec["scale"], spec["power"], coefs, g_x0_extra=g_sem)
+                g_unet = None
+                if model_out.requires_grad:
+                    (g_unet,) = torch.autograd.grad(model_out, x_prev,
+                                                    grad_outputs=pg.bufs[j].g_model_out.to(model_out.dtype))
+                    g_unet = kernels.f32c(g_unet, "UNet VJP")
+                pg.step_update(j, g_unet, coefs)
+        self._step_semantic = sems if sems else None
+        return pg.x_next(), pg.full.norm
+
     # -- the base loop (reference :175-303) -------------------------------------
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, **kwargs):
         img = x_start.detach()
@@ -297,6 +354,10 @@ class GaussianDiffusion:
         # DiffStateGrad (reference :203-204, 240-251): off by default; a projected step needs the gradient
         # itself, so it takes the per-op path; every other step keeps the fused launches
         period, project = kwargs.get('period', 20), kwargs.get('project', False)
+        # particle groups on streams (sampler.particle_groups > 1): only where every step is a fused step
+        pg = None
+        if plan is not None and self.particle_groups > 1 and img.shape[0] > 1 and not (project and returns_gradient):
+            pg = self._particle_group_set(plan[0], plan[1], img)
         for idx in steps:
             projecting = project and returns_gradient and period != 0 and idx % period == 0
             if plan is not None and not projecting:
@@ -304,8 +365,15 @@ class GaussianDiffusion:
                 if self.rng_parity:
                     # the reference's q_sample draw (:224), result unused by ps*
                     self._randn(measurement, self.parity_measurement_stride)
-                img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise,
-                                              want_x0=bool(record) and idx % 100 == 0)
+                snapshot = bool(record) and idx % 100 == 0
+                if pg is not None:
+                    img, distance = self.dps_step_grouped(model, img, idx, measurement, plan[0], plan[1], pg, noise,
+                                                          want_x0=snapshot)
+                    if snapshot:
+                        pg.join()
+                else:
+                    img, distance = self.dps_step(model, img, idx, measurement, plan[0], plan[1], plan[2], noise=noise,
+                                                  want_x0=snapshot)
                 if self._step_semantic is not None:
                     semantic = self._step_semantic
             else:
@@ -334,6 +402,10 @@ class GaussianDiffusion:
                 semantic = ret[2] if len(ret) > 2 and returns_gradient else semantic
             if record and idx % 100 == 0:
                 self._record(save_root, kwargs.get('path_curr_group_idx', 0), idx)
+        if pg is not None:
+            pg.join()
+            if isinstance(semantic, list):
+                semantic = torch.cat([v.reshape(-1) for v in semantic])
         # the fused step hands back views of the persistent ping-pong / norm buffers, which the next trajectory on
         # this sampler overwrites: what leaves the loop is a copy (one per 1000-step trajectory)
         img = img.clone()
@@ -349,7 +421,10 @@ class GaussianDiffusion:
             import matplotlib.pyplot as plt
         except ImportError:
             return
-        x0 = self._bufs[1].x0_hat[0] if self._bufs is not None else None
+        if self._pgroups is not None and self.particle_groups > 1:
+            x0 = self._pgroups[1].full.x0_hat[0]
+        else:
+            x0 = self._bufs[1].x0_hat[0] if self._bufs is not None else None
         if x0 is None or save_root is None:
             return
         a = x0.detach().float().cpu().numpy().transpose(1, 2, 0)
@@ -481,7 +556,7 @@ class SearchDDPM(DDPM):
         with torch.no_grad():
             model_out = self._call_model(model, state, idx)
         if noise is None:
-            noise = self._randn(torch.empty((n,) + tuple(state.shape[1:]), dtype=torch.float32, device=state.device))
+            noise = self._randn(state, shape=(n,) + tuple(state.shape[1:]))
         local = self.global_select is None
         winner, sample, costs, best, _ = handle.search_step_one(state, model_out, noise, measurement,
                                                                 self.step_coefs[idx], want_winner=local)
@@ -532,9 +607,9 @@ class SearchDDPM(DDPM):
                 ids = torch.multinomial(pot.cpu(), n, replacement=True).to(pot.device) if self.rng_parity \
                     else torch.multinomial(pot, n, replacement=True)
                 self.last_resample_ids = ids
-                candidates = kernels.gather(candidates, ids)
-                denoised_candidates = kernels.gather(denoised_candidates, ids)
-                prev_costs = kernels.gather(prev_costs.reshape(n, 1), ids).reshape(n)
+                candidates = kernels.gather(candidates, ids, validate=False)      # ids drawn above over [0, n)
+                denoised_candidates = kernels.gather(denoised_candidates, ids, validate=False)
+                prev_costs = kernels.gather(prev_costs.reshape(n, 1), ids, validate=False).reshape(n)
         mask = kwargs.get('mask', None)
         handle = operator.hip_handle_for(mask) if operator.name == 'inpainting' \
             else operator.hip_handle(denoised_candidates)
@@ -606,4 +681,4 @@ class TTC_DDIM(DDIM):
             drawn = torch.multinomial(torch.where(flat, torch.ones_like(weights), weights), n, replacement=True)
             ids = torch.where(flat, torch.arange(n, device=img.device), drawn)
         self.last_resample_ids = ids
-        return kernels.gather(img, ids), kernels.gather(distance.reshape(n, 1), ids).reshape(n)
+        return kernels.gather(img, ids, validate=False), kernels.gather(distance.reshape(n, 1), ids, validate=False).reshape(n)

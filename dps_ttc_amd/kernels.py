@@ -367,10 +367,11 @@ def argmin(v, want_value=False):
     return (out, val) if want_value else out
 
 
-def gather(src, ids, validate=False):
-    """src[ids] for an [N, ...] fp32 tensor and int64 ids (gaussian_diffusion.py:697).  No host sync: the kernel
-    never reads out of bounds (a bad id yields a NaN particle); validate=True adds torch's IndexError check
-    (two host reads) for ids that come from outside the package."""
+def gather(src, ids, validate=True):
+    """src[ids] for an [N, ...] fp32 tensor and int64 ids (gaussian_diffusion.py:697).  validate=True (the default for
+    ids that arrive through the public API) adds torch's IndexError check -- two host reads; the package's own loops pass
+    validate=False for ids they drew themselves (torch.multinomial over [0, N)): no host sync, and the kernel never reads
+    out of bounds anyway (a bad id yields a NaN particle)."""
     src = f32c(src)
     ids = ids.to(device=src.device, dtype=torch.int64).contiguous()
     if validate and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= src.shape[0]):
@@ -396,30 +397,50 @@ def replicate(src, idx_dev, n_out=None):
 
 # ------------------------------------------------------------------ fused DPS step
 class StepBuffers:
-    """Persistent per-(N, C, H, W) device buffers of the fused step (resident in HBM across steps)."""
+    """Persistent per-(N, C, H, W) device buffers of the fused step (resident in HBM across steps).
+    parent / offset: the buffers are the particle slice [offset, offset + n) of another StepBuffers (ParticleGroups: the
+    groups' sample / x_next / norm / g_model_out are contiguous slices of one full-batch set, so the UNet and the select see
+    [N, ...] tensors without a copy); the op-defined residual scratch is always the group's own."""
 
-    def __init__(self, handle, n, c, h, w, device):
+    def __init__(self, handle, n, c, h, w, device, parent=None, offset=0):
         self.shape = (n, c, h, w)
         f = dict(dtype=torch.float32, device=device)
-        self.x0_hat = torch.empty((n, c, h, w), **f)
-        self.sample = torch.empty((n, c, h, w), **f)
-        self.inside = torch.empty((n, c, h, w), dtype=torch.uint8, device=device)
-        self.norm = torch.empty(n, **f)
-        rb = lib().dpsx_step_resid_bytes(handle._h, n, c, h, w)
-        if rb < 0:
-            check(int(rb), "dpsx_step_resid_bytes")
+        if parent is None:
+            self.x0_hat = torch.empty((n, c, h, w), **f)
+            self.sample = torch.empty((n, c, h, w), **f)
+            self.inside = torch.empty((n, c, h, w), dtype=torch.uint8, device=device)
+            self.norm = torch.empty(n, **f)
+            # variance half of the UNet-output cotangent is identically zero for the DPS loss: zeroed once
+            self.g_model_out = torch.zeros((n, 2 * c, h, w), **f)
+            self.x_next = [torch.empty((n, c, h, w), **f), torch.empty((n, c, h, w), **f)]
+        else:
+            if tuple(parent.shape[1:]) != (c, h, w) or offset < 0 or offset + n > parent.shape[0]:
+                raise ValueError("particle slice outside the parent buffers")
+            sl = slice(offset, offset + n)
+            self.x0_hat, self.sample, self.inside = parent.x0_hat[sl], parent.sample[sl], parent.inside[sl]
+            self.norm, self.g_model_out = parent.norm[sl], parent.g_model_out[sl]
+            self.x_next = [parent.x_next[0][sl], parent.x_next[1][sl]]
+        rb = 0
+        if handle is not None:
+            rb = lib().dpsx_step_resid_bytes(handle._h, n, c, h, w)
+            if rb < 0:
+                check(int(rb), "dpsx_step_resid_bytes")
         self.resid = torch.empty(max(int(rb), 256), dtype=torch.uint8, device=device)
-        # variance half of the UNet-output cotangent is identically zero for the DPS loss: zeroed once
-        self.g_model_out = torch.zeros((n, 2 * c, h, w), **f)
-        self.x_next = [torch.empty((n, c, h, w), **f), torch.empty((n, c, h, w), **f)]
         self.flip = 0
 
 
 def _stream_arg(stream, t):
     """stream: None (torch's current stream on t's device -- a 4.5 us lookup per launch) or a torch.cuda.Stream, whose
     raw handle a caller that drives several particle groups passes explicitly instead of entering a stream context
-    (another 8 us per group and step: bench.py's three groups cost the host 96 us per step that way, 35 this way)."""
-    return stream_of(t) if stream is None else ctypes.c_void_p(stream.cuda_stream)
+    (another 8 us per group and step: three groups cost the host 96 us per step that way, 35 this way).
+    torch's caching allocator does not know about work enqueued this way: every tensor handed to a launch on a side stream
+    must outlive that stream's work or be marked with `t.record_stream(stream)` (ParticleGroups does both for what it
+    owns / is handed per step)."""
+    if stream is None:
+        return stream_of(t)
+    if stream.device != t.device:
+        raise ValueError(f"stream on {stream.device} given for tensors on {t.device}")
+    return ctypes.c_void_p(stream.cuda_stream)
 
 
 def step_fwd(handle, buf, x_t, model_out, noise, y, coefs, finalize_norm=False, want_x0=True, stream=None):
@@ -469,3 +490,88 @@ def step_update(buf, g_unet, coefs, stream=None):
     check(lib().dpsx_step_update_f32(ptr(buf.sample), ptr(buf.g_model_out), ptr(g_unet), ptr(out), n, c * h * w,
                                      byref(coefs), _stream_arg(stream, buf.sample)), "dpsx_step_update_f32")
     return out
+
+
+# ------------------------------------------------------------------ particle groups on streams
+class ParticleGroups:
+    """The N particles of a fused DPS loop as `groups` independent sub-batches, each with its own operator handle,
+    residual scratch and HIP stream (an operator handle, its workspace and its tail counters serve ONE stream at a time).
+
+    The three launches of a step depend on each other, the particles do not (no collective, no cross-particle term in
+    reference gaussian_diffusion.py:207-257), and the counters say every tile kernel's load / compute / store phases add
+    up inside one chain: side by side, the bandwidth-bound launch of one group fills the
+    arithmetic-bound phase of another.  Per-particle results do not depend on the grouping, bit for bit.
+    Used by `GaussianDiffusion.p_sample_loop` (sampler.particle_groups), the driver (--particle_groups) and bench.py.
+
+    All groups' sample / gate / norm / g_model_out / x_next are contiguous particle slices of ONE full-batch StepBuffers
+    (`self.full`): `self.full.norm` is the [N] distance vector and `self.x_next()` the [N, C, H, W] state, no copy."""
+
+    def __init__(self, operator, n, c, h, w, device, groups, mask=None, like=None, record_streams=True):
+        """record_streams=False: the caller keeps every tensor it hands to the launches alive until the groups are joined
+        (bench.py's device-resident rings), so the per-launch `record_stream` calls (about 1 us of host time each) are
+        skipped."""
+        device = torch.device(device)
+        self.record_streams = bool(record_streams)
+        groups = max(1, min(int(groups), max(n, 1)))
+        self.n, self.shape = n, (n, c, h, w)
+        self.sizes = [n // groups + (1 if j < n % groups else 0) for j in range(groups)]   # may differ by one particle
+        self.starts = [sum(self.sizes[:j]) for j in range(groups)]
+        self.slices = [slice(s, s + m) for s, m in zip(self.starts, self.sizes)]
+        self.full = StepBuffers(None, n, c, h, w, device)
+        probe = like if like is not None else self.full.sample
+        self.handles = [operator.new_hip_handle(probe, mask=mask) for _ in range(groups)]
+        self.bufs = [StepBuffers(hd, m, c, h, w, device, parent=self.full, offset=s)
+                     for hd, m, s in zip(self.handles, self.sizes, self.starts)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(groups)]
+        self.device = device
+
+    def __len__(self):
+        return len(self.bufs)
+
+    # -- ordering against the caller's stream
+    def fork(self, stream=None):
+        """every group's stream waits for the work enqueued so far on `stream` (default: torch's current stream)"""
+        cur = torch.cuda.current_stream(self.device) if stream is None else stream
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def join(self, stream=None):
+        """`stream` (default: torch's current stream) waits for every group's work"""
+        cur = torch.cuda.current_stream(self.device) if stream is None else stream
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def _slice(self, j, t):
+        """the group's particles of a full-batch tensor (a contiguous view); a tensor that already has the group's
+        size is taken as it is.  Tensors the caller allocates per step on its own stream are marked as in use by the
+        group's stream (the caching allocator would otherwise hand their memory out again while the launch reads it)."""
+        if t is None:
+            return None
+        if t.shape[0] == self.n and self.sizes[j] != self.n:
+            v = t[self.slices[j]]
+        elif t.shape[0] == self.sizes[j]:
+            v = t
+        else:
+            raise ValueError(f"tensor of {t.shape[0]} particles handed to a group of {self.sizes[j]} (batch of {self.n})")
+        if self.record_streams:
+            v.record_stream(self.streams[j])
+        return v
+
+    # -- the three launches of group j, on its stream
+    def step_fwd(self, j, x_t, model_out, noise, y, coefs, want_x0=True):
+        step_fwd(self.handles[j], self.bufs[j], self._slice(j, x_t), self._slice(j, model_out), self._slice(j, noise),
+                 y, coefs, want_x0=want_x0, stream=self.streams[j])
+
+    def step_bwd(self, j, y, scale, power, coefs, g_x0_extra=None):
+        step_bwd(self.handles[j], self.bufs[j], y, scale, power, coefs, g_x0_extra=self._slice(j, g_x0_extra),
+                 stream=self.streams[j])
+
+    def step_update(self, j, g_unet, coefs):
+        return step_update(self.bufs[j], self._slice(j, g_unet), coefs, stream=self.streams[j])
+
+    def x_next(self):
+        """[N, C, H, W]: the state the groups' last step_update calls wrote (all groups flip together)"""
+        flips = {b.flip for b in self.bufs}
+        if len(flips) != 1:
+            raise RuntimeError("the groups are not at the same step")
+        return self.full.x_next[flips.pop() ^ 1]

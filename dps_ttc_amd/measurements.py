@@ -50,6 +50,11 @@ class _HipOperator:
             self._handle = self._build_handle(data)
         return self._handle
 
+    def new_hip_handle(self, data=None, **kwargs):
+        """a fresh, uncached handle (own constant tables, workspace, tail counters): one per HIP stream that drives this
+        operator concurrently (kernels.ParticleGroups)"""
+        return self._build_handle(data)
+
     def _apply(self, data):
         return OperatorFn.apply(data, self.hip_handle(data))
 
@@ -200,6 +205,11 @@ class InpaintingOperator(LinearOperator):
             self._mask_key = key
         return self._handle
 
+    def new_hip_handle(self, data=None, **kwargs):
+        if kwargs.get('mask', None) is None:
+            raise ValueError("Require mask")
+        return OpHandle.mask(kwargs['mask'], self.device)
+
     def forward(self, data, **kwargs):
         mask = kwargs.get('mask', None)
         if mask is None:
@@ -238,6 +248,12 @@ class PhaseRetrievalOperator(NonLinearOperator):
             self._handle = OpHandle.phase(h, self.pad, max(n * c, 1), self.device)
             self._key = h
         return self._handle
+
+    def new_hip_handle(self, data=None, **kwargs):
+        n, c, h, w = data.shape
+        if h != w:
+            raise ValueError("phase_retrieval expects square images")
+        return OpHandle.phase(h, self.pad, max(n * c, 1), self.device)
 
     def forward(self, data, **kwargs):
         return self._apply(data)

@@ -9,6 +9,12 @@
  *     name ends in _host; the caller owns all buffers;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
  *     does no allocation and no host sync (graph-capturable);
+ *   - a dpsx_op serves ONE stream at a time: its workspace (caller-provided, sized by
+ *     dpsx_op_workspace_bytes) carries the per-tile partial sums from dpsx_step_fwd_f32 to
+ *     dpsx_step_bwd_f32, and its arrival counters belong to the launch in flight.  Calls on
+ *     one op must be stream-ordered; concurrency is across ops (one op + workspace per
+ *     stream -- kernels.ParticleGroups does exactly that).  Calls that take no op are
+ *     re-entrant;
  *   - return value: DPSX_OK or a negative DPSX_E* code; nothing throws/exits;
  *   - `n` = particles, `c` = channels, `h`,`w` = image size, chw = c*h*w.
  */

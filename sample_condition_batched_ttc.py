@@ -22,18 +22,23 @@ import argparse
 import os
 from functools import partial
 
-import numpy as np
-import torch
-import yaml
+# read by the HSA runtime when it initialises (first HIP call): must be in the environment before that, i.e. before anything
+# below touches the GPU -- the host driver only supports dmabuf IPC, RCCL fails with hipIpcGetMemHandle otherwise
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # one hardware queue per HIP stream (particle groups, RCCL)
 
-from dps_ttc_amd import distributed as dd
-from dps_ttc_amd.condition_methods import get_conditioning_method
-from dps_ttc_amd.data import get_dataloader, get_dataset, to_minus1_1
-from dps_ttc_amd.gaussian_diffusion import create_sampler
-from dps_ttc_amd.img_utils import clear_color, mask_generator
-from dps_ttc_amd.measurements import get_noise, get_operator
-from dps_ttc_amd.metrics import compute_psnr
-from dps_ttc_amd.unet import create_model
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from dps_ttc_amd import distributed as dd  # noqa: E402
+from dps_ttc_amd.condition_methods import get_conditioning_method  # noqa: E402
+from dps_ttc_amd.data import get_dataloader, get_dataset, to_minus1_1  # noqa: E402
+from dps_ttc_amd.gaussian_diffusion import create_sampler  # noqa: E402
+from dps_ttc_amd.img_utils import clear_color, mask_generator  # noqa: E402
+from dps_ttc_amd.measurements import get_noise, get_operator  # noqa: E402
+from dps_ttc_amd.metrics import compute_psnr  # noqa: E402
+from dps_ttc_amd.unet import create_model  # noqa: E402
 
 
 def load_yaml(file_path: str) -> dict:
@@ -86,6 +91,15 @@ def parse_args(argv=None):
     p.add_argument('--l1', type=float, default=0.0, help='(the reference reads args.l1 without defining it)')
     p.add_argument('--timestep_respacing', type=str, default=None, help='override the diffusion YAML (e.g. "100")')
     p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--embedder', type=str, default=None,
+                   help="'module:factory' -- factory(device) returns the embedding network of the semantic-guidance term "
+                        "(ps_semantic with sem_guid_scale != 0); default: facenet_pytorch's InceptionResnetV1 as in the reference")
+    p.add_argument('--guid_image', type=str, default=None,
+                   help='guidance image for --embedder (PNG, 256x256); default: the reference image itself (oracle guidance, '
+                        'for plumbing runs)')
+    p.add_argument('--particle_groups', type=int, default=1,
+                   help='run the batch_size particles of a fused DPS loop as this many independent sub-batches, each on its '
+                        'own HIP stream with its own operator handle (kernels.ParticleGroups; results per particle unchanged)')
     return p.parse_args(argv)
 
 
@@ -97,7 +111,6 @@ def main(argv=None):
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("DPSX_DIST_BACKEND", "nccl")      # "nccl" is RCCL; "gloo" only to rehearse on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -128,12 +141,20 @@ def main(argv=None):
     logger.info(f"Operation: {op_name} / Noise: {measure_config['noise']['name']}")
 
     cond_config = task_config['conditioning']
-    cond_method = get_conditioning_method(cond_config['method'], operator, noiser, **cond_config['params'])
+    cond_params = dict(cond_config['params'])
+    embedder = None
+    if args.embedder is not None:
+        import importlib
+        mod_name, _, fn_name = args.embedder.partition(':')
+        embedder = getattr(importlib.import_module(mod_name), fn_name)(device)
+        cond_params['embedder'] = embedder
+    cond_method = get_conditioning_method(cond_config['method'], operator, noiser, **cond_params)
     measurement_cond_fn = cond_method.conditioning
     logger.info(f"Conditioning method : {cond_config['method']}")
     logger.info(f"Sampling: {diffusion_config['sampler']} / Steps: {diffusion_config['steps']}")
 
     sampler = create_sampler(**diffusion_config)
+    sampler.particle_groups = max(1, args.particle_groups)
     groups = args.n_paths // args.batch_size
     if world > 1 and diffusion_config['sampler'] in ('search_ddpm', 'ttc_ddim'):
         # these loops exchange particles at every select / resample point: every rank runs the same number of groups
@@ -180,6 +201,13 @@ def main(argv=None):
         os.makedirs(os.path.join(out_path, 'recon_paths', fname), exist_ok=True)
         os.makedirs(os.path.join(out_path, 'recon_paths_y', fname), exist_ok=True)
 
+        if embedder is not None and hasattr(cond_method, 'guid_image_emb'):
+            guid = ref_img
+            if args.guid_image is not None:
+                from PIL import Image
+                guid = to_minus1_1(Image.open(args.guid_image).convert('RGB')).unsqueeze(0).to(device)
+            with torch.no_grad():
+                cond_method.guid_image_emb = embedder(guid).unsqueeze(0)        # [1, n_guid = 1, D]
         fkw = {}
         this_sample_fn = sample_fn
         if op_name == 'inpainting':

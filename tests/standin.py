@@ -32,6 +32,26 @@ class StandInModel(torch.nn.Module):
         return torch.cat([eps, v], dim=1)
 
 
+class ToyEmbedder(torch.nn.Module):
+    """Stand-in for the reference's face-embedding network (facenet_pytorch InceptionResnetV1, not available offline):
+    average-pool to 8 x 8, a fixed random linear map to 16 features, tanh.  Differentiable, deterministic (seeded
+    weights), batch-independent -- enough to drive the semantic-guidance term's plumbing end to end."""
+
+    def __init__(self, dim=16, seed=5):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.register_buffer("w", torch.randn(3 * 8 * 8, dim, generator=g) / 8.0)
+
+    def forward(self, x):
+        f = torch.nn.functional.adaptive_avg_pool2d(x.float(), 8).reshape(x.shape[0], -1)
+        return torch.tanh(f @ self.w)
+
+
+def toy_embedder(device):
+    """factory for the driver's --embedder flag (module:callable)"""
+    return ToyEmbedder().to(device).eval()
+
+
 def synthetic_motion_kernel(size=61, seed=0, steps=120):
     """Random-walk path rasterised with bilinear splats, normalised to sum 1."""
     rng = np.random.RandomState(seed)

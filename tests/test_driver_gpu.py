@@ -135,22 +135,41 @@ def test_consecutive_loops_do_not_share_storage():
     assert not torch.equal(outs[0][0], outs[1][0])
 
 
-@pytest.mark.parametrize("sampler,n_paths,batch", [("ddpm", 3, 1), ("search_ddpm", 4, 2), ("ttc_ddim", 4, 2)])
-def test_driver_two_ranks(tmp_path, sampler, n_paths, batch):
+@pytest.mark.parametrize("task,sampler,n_paths,batch,extra", [
+    ("gaussian_deblur_config.yaml", "ddpm", 3, 1, ()),
+    ("gaussian_deblur_config.yaml", "search_ddpm", 4, 2, ()),
+    ("gaussian_deblur_config.yaml", "ttc_ddim", 4, 2, ()),
+    # BASELINE configs[3] in its sharded form: motion deblur + ACTIVE semantic-guidance term (anneal 10x) -- the embedder is
+    # a stand-in (the reference's face network is not available offline), everything else is the shipped YAML
+    ("motion_deblur_config_semantic.yaml", "ddpm", 4, 2, ("--embedder", "tests.standin:toy_embedder")),
+    ("motion_deblur_config_semantic.yaml", "search_ddpm", 4, 2, ("--embedder", "tests.standin:toy_embedder")),
+    # BASELINE configs[4] in its sharded form: phase retrieval + global multinomial resampling over all ranks' particles
+    ("phase_retrieval_config.yaml", "ttc_ddim", 4, 2, ()),
+    ("phase_retrieval_config.yaml", "search_ddpm", 4, 2, ()),
+])
+def test_driver_two_ranks(tmp_path, task, sampler, n_paths, batch, extra):
     """two rank processes (gloo rehearsal on one GPU): uneven group shards for the independent-particle loop (3 groups
     on 2 ranks), per-step global select for search_ddpm, global resampling for ttc_ddim; path numbering is global and
     the best-of-N image is the reported path's."""
-    task = "gaussian_deblur_config.yaml"
-    root, logs = _run_driver(tmp_path, task, sampler, n_paths, batch, ranks=2)
+    root, logs = _run_driver(tmp_path, task, sampler, n_paths, batch, ranks=2, extra=extra)
     best = _check_best_of_n(root, n_paths) if sampler == "ddpm" else None
     d = np.load(root / "00000_pathwise_distances.npy")
-    assert d.shape == (n_paths,)
+    assert d.shape == (n_paths,) and np.isfinite(d).all()
     assert f"best-of-{n_paths} = path#{int(np.argmin(d)) + 1} " in logs[0]
     if sampler == "search_ddpm":
         # every particle of every rank ends as a copy of the global per-step winner: all distances agree
         assert np.allclose(d, d[0], rtol=1e-6)
-    if best is not None:
+    if best is not None and n_paths == 3:
         assert "Path#3 " in logs[1] and "Path#1 " in logs[0] and "Path#2 " in logs[0]
+    if best is not None and n_paths == 4:
+        assert "Path#3 " in logs[1] and "Path#4 " in logs[1] and "Path#1 " in logs[0]
+
+
+def test_driver_particle_groups_flag(tmp_path):
+    """--particle_groups 2: the batch's particles as two sub-batches on two HIP streams inside p_sample_loop
+    (kernels.ParticleGroups); same outputs tree, finite distances"""
+    root, logs = _run_driver(tmp_path, "gaussian_deblur_config.yaml", "ddpm", 4, 4, extra=("--particle_groups", "2"))
+    _check_best_of_n(root, 4)
 
 
 def test_bench_self_launch_two_ranks():
@@ -170,11 +189,61 @@ def test_bench_self_launch_two_ranks():
     assert rec["value"] > 0 and 0 <= rec["best_of_n_index"] < 8 and "roofline" in rec
 
 
-@pytest.mark.parametrize("explicit", [False, True])
-@pytest.mark.parametrize("operator", ["gaussian_blur", "motion_blur"])
-def test_particle_groups_on_streams_match_one_chain(operator, explicit):
-    """bench.py's timed loop runs the particles as independent groups on separate HIP streams (own operator handle and
-    buffers each): per-particle results must not depend on the grouping -- x_{t-1} and the distances bit for bit."""
+@pytest.mark.parametrize("mode", [
+    # BASELINE configs[3]: motion blur, N sharded (strong scaling), semantic stand-in, per-step score all-gather
+    ["--workload", "dps_scores", "--operator", "motion_blur", "--scaling", "strong", "--particles", "6", "--semantic"],
+    # per-step best-of-N with the global select inside the timed region
+    ["--workload", "search", "--operator", "motion_blur", "--scaling", "strong", "--particles", "6"],
+    # BASELINE configs[4]: phase retrieval, global resampling every 2 steps inside the timed region
+    ["--workload", "resample", "--operator", "phase_retrieval", "--particles", "3", "--resample-every", "2"],
+])
+def test_bench_sharded_workloads_two_ranks(mode):
+    """the timed search / resample / per-step-score modes of bench.py, two gloo ranks on this box's one GPU: the
+    collectives of distributed.py run inside the timed region and the line says so"""
+    import json
+    import subprocess
+    env = dict(os.environ, DPSX_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", *mode], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and np.isfinite(rec["ms_per_step"])
+    assert rec["config"]["step"] == mode[1] and rec["config"]["global_particles"] == 6
+    assert rec["scaling"] == ("strong" if "strong" in mode else "weak")
+    assert rec["config"]["particles_per_gpu"] == 3 and rec["config"]["chains_per_gpu"] == 1
+    assert 0 <= rec["best_of_n_index"] < 6 and "roofline" in rec
+
+
+def test_bench_line_carries_both_schedules():
+    """one GPU, default workload: the line has the grouped step (value) AND the one-chain step, the survey-priced AND the
+    moved-bytes fraction (profiles/traffic.json holds the Gaussian operator's PMC bytes)"""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
+    rf = rec["roofline"]
+    assert rec["config"]["chains_per_gpu"] == 3 and rec["config"]["x0_hat_store"] is False
+    for key in ("one_chain_ms_per_step", "one_chain_value", "step_moved_bytes_per_particle", "step_moved_GBps",
+                "step_frac_moved", "step_frac_of_hbm_roofline", "frac_of_copy_ceiling"):
+        assert key in rf and rf[key] > 0, key
+    assert rf["one_chain_ms_per_step"] > 0.5 * rec["ms_per_step"]
+    for k, v in rf["per_launch"].items():
+        assert v["moved_bytes"] and v["moved_GBps"] < 8000.0 and v["algorithmic_GBps"] < 8000.0, (k, v)
+    assert rf["step_frac_moved"] < rf["step_frac_of_hbm_roofline"] <= 1.0
+
+
+@pytest.mark.parametrize("operator", ["gaussian_blur", "motion_blur", "inpainting"])
+def test_particle_groups_on_streams_match_one_chain(operator):
+    """kernels.ParticleGroups (what sampler.particle_groups, the driver's --particle_groups and bench.py's timed loop
+    run): the particles as independent groups on separate HIP streams, own operator handle and residual scratch each --
+    per-particle results must not depend on the grouping: x_{t-1} and the distances bit for bit."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
@@ -184,41 +253,74 @@ def test_particle_groups_on_streams_match_one_chain(operator, explicit):
     smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
                          model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
                          rescale_timesteps=True, timestep_respacing="")
-    n, steps = 6, 4
+    n, steps = 7, 4
     x_t, ring, truth, meas_noise = bench.synth_inputs(n, 2, dev, 77)
+    op, fkw = bench.build_operator(operator, dev)
+    mask = fkw.get("mask")
+    handle = op.hip_handle_for(mask) if operator == "inpainting" else op.hip_handle(x_t)
+    buf = kernels.StepBuffers(handle, n, 3, 256, 256, dev)
+    y = (op.forward(truth.to(dev), **fkw).detach() + meas_noise.to(dev)[..., :256, :256]).contiguous()
+    x = x_t
+    for i in range(steps):
+        ck = smp.step_coefs[999 - 300 * i]
+        s = ring[i % 2]
+        kernels.step_fwd(handle, buf, x, s["model_out"], s["noise"], y, ck, want_x0=False)
+        kernels.step_bwd(handle, buf, y, 0.3, 1, ck)
+        x = kernels.step_update(buf, s["g_unet"], ck)
+    ref, ref_norm = x.clone(), buf.norm.clone()
+    for groups in (2, 3):
+        pg = kernels.ParticleGroups(op, n, 3, 256, 256, dev, groups, mask=mask, like=x_t)
+        assert sum(pg.sizes) == n and max(pg.sizes) - min(pg.sizes) <= 1
+        pg.fork()
+        xs = [x_t[sl] for sl in pg.slices]
+        for i in range(steps):
+            ck = smp.step_coefs[999 - 300 * i]
+            s = ring[i % 2]
+            for j in range(len(pg)):
+                pg.step_fwd(j, xs[j], s["model_out"], s["noise"], y, ck, want_x0=False)
+                pg.step_bwd(j, y, 0.3, 1, ck)
+                xs[j] = pg.step_update(j, s["g_unet"], ck)
+        pg.join()
+        torch.cuda.synchronize()
+        assert torch.equal(pg.x_next(), ref), groups
+        assert torch.equal(pg.full.norm, ref_norm), groups
 
-    def make(count):
-        op, fkw = bench.build_operator(operator, dev)
-        handle = op.hip_handle(x_t)
-        return op, handle, kernels.StepBuffers(handle, count, 3, 256, 256, dev)
 
-    op, handle, buf = make(n)
-    y = (op.forward(truth.to(dev)).detach() + meas_noise.to(dev)[..., :256, :256]).contiguous()
-
-    def run(handle, buf, x, sl, stream):
-        # explicit: the stream is handed to the launches (kernels.step_*(stream=), what bench.py does); else a stream context
-        import contextlib
-        kw = {"stream": stream} if explicit else {}
-        with (contextlib.nullcontext() if explicit else torch.cuda.stream(stream)):
-            for i in range(steps):
-                ck = smp.step_coefs[999 - 300 * i]
-                s = ring[i % 2]
-                kernels.step_fwd(handle, buf, x, s["model_out"][sl], s["noise"][sl], y, ck, want_x0=not explicit, **kw)
-                kernels.step_bwd(handle, buf, y, 0.3, 1, ck, **kw)
-                x = kernels.step_update(buf, s["g_unet"][sl], ck, **kw)
-        return x
-
-    ref = run(handle, buf, x_t, slice(0, n), torch.cuda.current_stream()).clone()
-    ref_norm = buf.norm.clone()
+@pytest.mark.parametrize("operator,semantic", [("gaussian_blur", False), ("motion_blur", True)])
+def test_sampler_particle_groups_equal_one_chain(operator, semantic):
+    """sampler.particle_groups = 3: p_sample_loop runs every group's whole step (model call, three launches, model VJP) on
+    the group's own stream; the loop's outputs equal the one-chain loop's bit for bit (same noise draws, per-particle
+    arithmetic independent of the batch)."""
+    import torch
+    from standin import StandInModel, ToyEmbedder
+    sys.path.insert(0, ROOT)
+    import bench
+    from dps_ttc_amd.condition_methods import get_conditioning_method
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    from dps_ttc_amd.measurements import get_noise
+    dev = torch.device("cuda", 0)
+    op, _ = bench.build_operator(operator, dev)
+    kw = {}
+    if semantic:
+        emb = ToyEmbedder().to(dev)
+        kw = dict(sem_guid_scale=0.05, anneal_factor=10.0, embedder=emb,
+                  guid_image_emb=emb(torch.rand(1, 3, 64, 64, device=dev)).unsqueeze(0))
+    cm = get_conditioning_method("ps_semantic" if semantic else "ps", op, get_noise("gaussian", sigma=0.05), scale=0.3, **kw)
+    model = StandInModel().to(dev)
+    y = torch.rand(1, 3, 64, 64, device=dev)
     outs = []
-    for j in range(2):
-        _, h2, b2 = make(n // 2)
-        st = torch.cuda.Stream(device=dev)
-        st.wait_stream(torch.cuda.current_stream())
-        sl = slice(j * n // 2, (j + 1) * n // 2)
-        outs.append((run(h2, b2, x_t[sl], sl, st), b2, st))
-    for _, _, st in outs:
-        torch.cuda.current_stream().wait_stream(st)
-    torch.cuda.synchronize()
-    assert torch.equal(torch.cat([o[0] for o in outs]), ref)
-    assert torch.equal(torch.cat([o[1].norm for o in outs]), ref_norm)
+    for groups in (1, 3):
+        smp = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                             model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                             rescale_timesteps=True, timestep_respacing="6")
+        smp.particle_groups = groups
+        torch.manual_seed(11)
+        x0 = torch.randn(5, 3, 64, 64, device=dev)
+        img, d, sem = smp.p_sample_loop(model=model, x_start=x0.clone().requires_grad_(), measurement=y,
+                                        measurement_cond_fn=cm.conditioning, record=False, save_root=None)
+        torch.cuda.synchronize()
+        outs.append((img, d, sem))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[0][0]).all())
+    if semantic:
+        assert torch.equal(outs[0][2].reshape(-1), outs[1][2].reshape(-1))

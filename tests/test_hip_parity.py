@@ -776,8 +776,10 @@ def test_argmin_gather_replicate(K, oracle, golden):
     assert K.gather(src4, ids[:0]).shape == (0, 3, 8, 8)
     assert torch.equal(K.replicate(src4, torch.tensor(2, device=DEV)), src4[2:3].repeat(6, 1, 1, 1))
     with pytest.raises(IndexError):
-        K.gather(src4, torch.tensor([6], device=DEV), validate=True)
-    bad = K.gather(src4, torch.tensor([1, 6, -1], device=DEV))      # no host check: a bad id poisons its particle only
+        K.gather(src4, torch.tensor([6], device=DEV))                  # the public default validates (torch's IndexError)
+    with pytest.raises(IndexError):
+        K.gather(src4, torch.tensor([-1], device=DEV))
+    bad = K.gather(src4, torch.tensor([1, 6, -1], device=DEV), validate=False)   # the loops' own ids: no host check; a bad id poisons its particle only
     assert torch.equal(bad[0], src4[1]) and bool(torch.isnan(bad[1:]).all())
     idx, val = K.argmin(v, want_value=True)
     assert int(idx) == 1 and val.shape == (1,) and float(val) == 1.0

@@ -44,16 +44,18 @@ def main():
     handle = op.hip_handle_for(fkw["mask"]) if args.operator == "inpainting" else op.hip_handle(x_t)
     buf = kernels.StepBuffers(handle, n, 3, 256, 256, dev)
     ck = smp.step_coefs[500]
-    rho = y[0].numel() / x_t[0].numel()
     P = bench.P_BYTES
+    # one byte table for bench.py and this tool (bench.algo_p): the configuration launched (x0_hat store on / off)
+    tbl = bench.algo_p(args.operator, x0_store=not args.no_x0)["algorithmic"]
+    rho = bench.RHO[args.operator]
     u = torch.randn((n,) + tuple(y.shape[1:]), device=dev)
     cases = {
         "fwd": (lambda i: kernels.step_fwd(handle, buf, x_t, ring[i % 2]["model_out"], ring[i % 2]["noise"], y, ck,
-                                           finalize_norm=args.norm_in_fwd, want_x0=not args.no_x0), (7 + rho) * P),
+                                           finalize_norm=args.norm_in_fwd, want_x0=not args.no_x0), tbl["fwd"] * P),
         # as in the loop: the norm is finalised from the forward half's partials (--norm-in-fwd: by K1's own tail)
         "bwd": (lambda i: (setattr(buf, "norm_ready", args.norm_in_fwd), kernels.step_bwd(handle, buf, y, 0.3, 1, ck)),
-                (4 + rho) * P),
-        "upd": (lambda i: kernels.step_update(buf, ring[i % 2]["g_unet"], ck), 4 * P),
+                tbl["bwd"] * P),
+        "upd": (lambda i: kernels.step_update(buf, ring[i % 2]["g_unet"], ck), tbl["upd"] * P),
         "op": (lambda i: handle.forward(x_t), (1 + rho) * P),
         "adj": (lambda i: handle.adjoint(u, x=x_t, in_hw=(256, 256)), (1 + rho) * P),
         "score": (lambda i: handle.score(x_t, y), 1 * P),
@@ -71,8 +73,9 @@ def main():
             b.record()
         torch.cuda.synchronize()
         ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+        label = f", x0_hat store {'off' if args.no_x0 else 'on'}" if name in ("fwd", "bwd") else ""
         print(f"{name:6s} avg {ts.mean():8.1f} us  min {ts.min():8.1f} us   "
-              f"{bytes_pp * n / ts.mean() / 1e3:8.1f} GB/s algorithmic ({bytes_pp / P:.2f} P/particle)", flush=True)
+              f"{bytes_pp * n / ts.mean() / 1e3:8.1f} GB/s algorithmic ({bytes_pp / P:.2f} P/particle{label})", flush=True)
 
 
 if __name__ == "__main__":

@@ -589,7 +589,8 @@ int dpsx_step_bwd_extra_f32(dpsx_op *op, const void *resid, const float *norm, f
     int parts = (int)parts_per_particle(op, c, h, w);
     if (op->kind == OP_IDENT || op->kind == OP_PHASE) {
         if (op->kind == OP_IDENT) parts = 64;
-        if (!norm) {                      // these two have no fused prologue: finalise with the small kernel
+        // (the hand-written spectral phase step finalises the norm in its backward launch's prologue)
+        if (!norm && !(op->kind == OP_PHASE && phase_norm_in_bwd(op))) {     // no fused prologue: finalise with the small kernel
             if ((rc = finalize_norm(ws.partials, parts, norm_out, n, s)) != DPSX_OK) return rc;
             norm = norm_out;
         }

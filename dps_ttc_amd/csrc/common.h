@@ -461,6 +461,7 @@ int phase_adjoint(dpsx_op *op, const float *u, const float *x, float *g, int64_t
 int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_t s);   // S1 included
 bool phase_vec4_ok(const dpsx_op *op);
 bool phase_is_spectral(const dpsx_op *op);
+bool phase_norm_in_bwd(const dpsx_op *op);   // the backward launch finalises the norm from the partial sums itself
 int phase_step_bwd_fused(dpsx_op *op, float *resid_c, const StepBwdArgs &b, hipStream_t s);
 int phase_step_bwd(dpsx_op *op, float *resid_c, float *g_x0, int64_t planes, hipStream_t s);
 int64_t phase_parts_per_particle(const dpsx_op *op, int64_t c);

@@ -37,6 +37,14 @@ static bool spectral(const dpsx_op *op)
 }
 
 
+// A/B switch (tools/kbench.py): the round-2 passes B and C of the hand-written spectral step
+static bool phase_v1()
+{
+    static const bool on = getenv("DPSX_PHASE_V1") != nullptr;
+    return on;
+}
+bool phase_norm_in_bwd(const dpsx_op *op) { return spectral(op) && !phase_v1(); }
+
 static int get_plan(dpsx_op *op, int64_t planes, hipfftHandle *out, int kind = 0)
 {
     PhaseHost *h = host_of(op);
@@ -410,8 +418,13 @@ int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_
             f.x_t, f.model_out, f.noise, f.x0_hat, f.sample, f.inside, hbuf, tw, (int)c, f.k);
         if ((rc = check_launch()) != DPSX_OK) return rc;
         const unsigned tiles = (prfft::HS + prfft::CT - 1) / prfft::CT;
-        const size_t lds = (size_t)(prfft::N + prfft::N * prfft::CT) * sizeof(float2);
-        prfft::k_pr_cols<<<dim3(tiles, (unsigned)planes), prfft::BT, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
+        if (phase_v1()) {
+            const size_t lds = (size_t)(prfft::N + prfft::N * prfft::CT) * sizeof(float2);
+            prfft::k_pr_cols<<<dim3(tiles, (unsigned)planes), prfft::BT, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
+            return check_launch();
+        }
+        const size_t lds = (size_t)prfft::B2LDS * sizeof(float2);
+        prfft::k_pr_cols2<<<dim3(tiles, (unsigned)planes), prfft::B2T, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
         return check_launch();
     }
     if (vec) {      // S1 and the transform's input staging in one pass
@@ -443,9 +456,17 @@ int phase_step_bwd_fused(dpsx_op *op, float *resid_c, const StepBwdArgs &b, hipS
     const int64_t planes = b.n * b.c;
     if (planes == 0) return DPSX_OK;
     if (spectral(op)) {              // pass C
-        prfft::k_pr_rows_inv<<<dim3(prfft::IMG / prfft::RPB, (unsigned)planes), 256, 0, s>>>(
-            reinterpret_cast<const float2 *>(resid_c), b.norm, b.inside, b.g_extra, b.scale, b.power, -b.k.b,
-            b.g_model_out, host_of(op)->d_tw, (int)b.c);
+        if (phase_v1()) {
+            if (!b.norm) return DPSX_EINVAL;
+            prfft::k_pr_rows_inv<<<dim3(prfft::IMG / prfft::RPB, (unsigned)planes), 256, 0, s>>>(
+                reinterpret_cast<const float2 *>(resid_c), b.norm, b.inside, b.g_extra, b.scale, b.power, -b.k.b,
+                b.g_model_out, host_of(op)->d_tw, (int)b.c);
+            return check_launch();
+        }
+        // b.norm == nullptr: the launch finalises the per-particle norm from the forward half's partial sums itself
+        prfft::k_pr_rows_inv2<<<dim3(prfft::IMG / prfft::C2ROWS, (unsigned)planes), prfft::C2T, 0, s>>>(
+            reinterpret_cast<const float2 *>(resid_c), b.norm, b.partials, b.parts, b.norm_out, b.inside, b.g_extra,
+            b.scale, b.power, -b.k.b, b.g_model_out, host_of(op)->d_tw, (int)b.c);
         return check_launch();
     }
     const int h = (int)op->pr_h, pad = (int)op->pr_pad, sz = h + 2 * pad;

@@ -20,6 +20,9 @@
 namespace prfft {
 
 constexpr int N = 384, HS = 193, IMG = 256, PADW = 64, HALF = 192, CT = 16;
+// row pitch of the half-spectrum scratch [planes][256][HP]: 208 complex = 13 x 128 B, so the 16-column (128 B) tiles of pass B
+// are whole cache lines (with the natural pitch of 193 a tile row straddled two lines: the PMC pass counted 1.5 x the array)
+constexpr int HP = 208;
 
 // complex values as 2-vectors: additions are one v_pk_add_f32, products a v_pk_mul_f32 + v_pk_fma_f32 pair
 typedef float cf __attribute__((ext_vector_type(2)));
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void k_pr_rows_fwd(const float *__restrict__ x
     const int sub = lane / LPR, l = lane - sub * LPR;      // this lane's row within the wave, lane within the row
     float2 *row = s_row[wave * RPW + sub];
     fft_fwd<1>(row, s_tw, l, LPR);
-    float2 *out = half + (plane * IMG + a0 + sub) * HS;
+    float2 *out = half + (plane * IMG + a0 + sub) * HP;
     for (int kx = l; kx < HS; kx += LPR) out[kx] = row[pos_of_freq(kx)];
 }
 
@@ -264,13 +267,13 @@ __global__ __launch_bounds__(BT) void k_pr_cols(float2 *__restrict__ half, const
     const int kx = tile * CT + cl;
     const bool colok = kx < HS;
     for (int i = threadIdx.x; i < N; i += BT) s_tw[i] = tw_g[i];
-    float2 *hp = half + plane * IMG * HS;
+    float2 *hp = half + plane * IMG * HP;
     {
         constexpr int RPL = IMG / (TPC);      // 16 image rows per lane, loads first
         float2 t[RPL];
         const int kxc = colok ? kx : HS - 1;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) t[i] = hp[(int64_t)(g + i * (TPC)) * HS + kxc];
+        for (int i = 0; i < RPL; ++i) t[i] = hp[(int64_t)(g + i * (TPC)) * HP + kxc];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) s_d[shifted(g + i * (TPC)) * CT + cl] = colok ? t[i] : make_float2(0.0f, 0.0f);
     }
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(BT) void k_pr_cols(float2 *__restrict__ half, const
     __syncthreads();
     fft_inv<CT>(s_d + cl, s_tw, g, TPC);
     if (colok)
-        for (int a = g; a < IMG; a += TPC) hp[(int64_t)a * HS + kx] = s_d[shifted(a) * CT + cl];
+        for (int a = g; a < IMG; a += TPC) hp[(int64_t)a * HP + kx] = s_d[shifted(a) * CT + cl];
     const float t = dpsx::block_sum(acc, scratch);
     if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
 }
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void k_pr_rows_inv(const float2 *__restrict__ 
     {
         const int sub = lane / LPR, l = lane - sub * LPR;
         float2 *row = s_row[wave * RPW + sub];
-        const float2 *in = half + (plane * IMG + a0 + sub) * HS;
+        const float2 *in = half + (plane * IMG + a0 + sub) * HP;
         for (int kx = l; kx < HS; kx += LPR) {
             const float2 v = in[kx];
             row[pos_of_freq(kx)] = v;
@@ -361,6 +364,257 @@ __global__ __launch_bounds__(256) void k_pr_rows_inv(const float2 *__restrict__ 
         g.z = gate.z ? neg_b * (coef * row[v0 + 2].x + ex.z) : 0.0f;
         g.w = gate.w ? neg_b * (coef * row[v0 + 3].x + ex.w) : 0.0f;
         *reinterpret_cast<float4 *>(g_mo + (n * 2 * c + ch) * hw + (int64_t)(a0 + r) * IMG + 4 * lane) = g;
+    }
+}
+
+// =====================================================================================================================
+// Round 3: passes B and C rebuilt around REGISTERS instead of LDS passes.
+//
+// What the round-2 kernels above paid for (SQ counters, profiles/r03_sq_phase_retrieval_*): every FFT level was an
+// LDS read + an LDS write of the whole array behind a workgroup barrier (pass B: six writes and six reads per element,
+// seven barriers), and the 32 lanes that shared one transform were 75 % (24 radix-16 butterflies) and 50 % (16 radix-24
+// blocks) busy.  Here a transform belongs to SIXTEEN lanes:
+//   level 2 (16 radix-24 blocks)      one block per lane -- and everything that happens to a frequency happens in that
+//                                     lane's registers: forward DFT24, modulus / residual / cotangent, inverse DFT24;
+//   level 1 (24 radix-16 butterflies) two rounds (16 + 8): inputs come straight from global memory (forward) and the
+//                                     outputs go straight back (inverse) -- the stride-24 gather IS the global access,
+//                                     the known-zero inputs (the 128 padding rows / columns) are never loaded;
+// so the array crosses LDS only for the transposition between the two levels: two writes and two reads per element, two
+// barriers.  Pass C also puts TWO image rows into one complex transform (both spectra are Hermitian, so row r1 comes
+// out as the real part and r2 as the imaginary part of the inverse of X1 + i X2): half the transforms.
+// =====================================================================================================================
+constexpr int G16 = 16;                     // lanes per transform
+// LDS index of position p = 24 q + k = j + 24 q in the row kernels (one transform = 384 contiguous float2): element k of
+// block q sits at 24 q + (k + q) mod 24.  The 16 lanes of a transform read "their" k of blocks q = 0..15 together: without
+// the rotation they are 48 words apart (four lanes per bank pair -- the round-2 row kernels spent 60 % of their LDS cycles
+// in bank conflicts, profiles/r03_sq_phase_retrieval_bwd_summary.txt); with it 50 words, all distinct except where the
+// rotation wraps.  No padding: 3 KB per transform, three 16-transform workgroups per CU.
+__device__ __forceinline__ int rot24(int q, int k) { const int r = k + q; return 24 * q + (r >= 24 ? r - 24 : r); }
+
+// rows of the shifted (ifftshift + zero padding) axis: u in [0, 128) is image index u + 128, u in [256, 384) is u - 256,
+// u in [128, 256) is padding.  For a level-1 butterfly j its inputs u = j + 24 m are therefore: m <= 4 image, m = 5 image
+// iff j < 8, m = 6..9 padding, m = 10 image iff j >= 16, m >= 11 image -- compile-time per m except for those two.
+__device__ __forceinline__ bool lvl1_is_image(int j, int m) { return m <= 4 || (m == 5 && j < 8) || (m == 10 && j >= 16) || m >= 11; }
+__device__ __forceinline__ int lvl1_image_index(int j, int m) { const int u = j + 24 * m; return u < 128 ? u + 128 : u - 256; }
+
+// ---- pass B: one (plane, 16-column tile) per 256-thread block; lane (cl, g): column cl of the tile, level-2 block g,
+// level-1 butterflies g and (waves 0, 1 only) g + 16.  LDS: twiddles | s_d[384][16] (row swizzle: b2_idx1 / b2_idx2).
+constexpr int B2T = 256, B2LDS = N + N * CT;     // float2 elements of dynamic LDS: twiddles | 384 rows x 16 columns
+
+// position p = j + 24 q (level 1: butterfly j, output q) = 24 q + k (level 2: block q, element k) sits in LDS row
+// 24 q + (k ^ (q & 1)): a row of 16 columns is 32 words, so rows of equal parity share their banks -- and the two blocks
+// q, q + 1 that share a ds_read_b64 half-wave in level 2 read the same k.  Swapping the row pairs of the odd blocks puts
+// them on opposite halves of the banks without a padding row: 52,224 B with the twiddles, three workgroups per CU (LDS is
+// granted in 512-byte granules: the padded 54,288 B image admitted only two -- 91 us instead of 66).
+__device__ __forceinline__ int b2_idx1(int j, int q, int cl) { return (24 * q + (j ^ (q & 1))) * CT + cl; }
+// (level 2, block q runtime, k compile-time: k ^ b = k + b for even k, k - b for odd k -- two base registers + immediates)
+__device__ __forceinline__ int b2_idx2(int be, int bo, int k) { return ((k & 1) ? bo : be) + k * CT; }
+
+__global__ __launch_bounds__(B2T, 3) void k_pr_cols2(float2 *__restrict__ half, const float *__restrict__ y, int y_n, int c,
+                                                      float *__restrict__ partials, const float2 *__restrict__ tw_g)
+{
+    extern __shared__ __align__(16) float2 s_dyn[];
+    float2 *s_tw = s_dyn, *s_d = s_dyn + N;
+    __shared__ float scratch[B2T / dpsx::kWave];
+    const int64_t plane = blockIdx.y;
+    const int tile = blockIdx.x, cl = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
+    const int kx = tile * CT + cl;
+    const bool colok = kx < HS;
+    const int kxc = colok ? kx : HS - 1;            // surplus lanes of the last tile shadow its last column (never stored)
+    for (int i = threadIdx.x; i < N; i += B2T) s_tw[i] = tw_g[i];
+    float2 *hp = half + plane * IMG * HP + kxc;
+    __syncthreads();                                 // twiddles
+    // ---- forward level 1, inputs from global memory
+    for (int j = g; j < 24; j += G16) {              // second round: waves 0 and 1 only (wave-uniform)
+        cf x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            x[m] = cf{0.0f, 0.0f};
+            if (m <= 4 || m >= 11) x[m] = ld(hp + (int64_t)lvl1_image_index(j, m) * HP);
+            else if (m == 5 || m == 10) {
+                // (both index forms stay inside the plane: the load is unconditional, the value selected)
+                const cf v = ld(hp + (int64_t)(m == 5 ? (j + 120 + 128) & 255 : (j + 240 - 256) & 255) * HP);
+                x[m] = lvl1_is_image(j, m) ? v : cf{0.0f, 0.0f};
+            }
+        }
+        dft16<true>(x);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], ld(s_tw + j * q));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) st(s_d + b2_idx1(j, q, cl), x[q]);
+    }
+    const int n = (int)(plane / c), ch = (int)(plane % c);
+    const float *yp = y + ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * N * N;
+    // the measurement values of this lane's 24 frequencies and of their mirrors (an L2-resident table: 1.8 MB for a broadcast
+    // measurement): issued ahead of the barrier, so that their latency runs under the wait and the forward DFT24
+    float y1[24], y2[24];
+    {
+        const int mx = kxc == 0 ? 0 : N - kxc;
+        int ox = kxc + HALF, px = mx + HALF;
+        ox = ox >= N ? ox - N : ox;
+        px = px >= N ? px - N : px;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int ky = g + 16 * k, my = ky == 0 ? 0 : N - ky;
+            int oy = ky + HALF, py = my + HALF;
+            oy = oy >= N ? oy - N : oy;
+            py = py >= N ? py - N : py;
+            y1[k] = yp[oy * N + ox];
+            y2[k] = yp[py * N + px];
+        }
+    }
+    __syncthreads();
+    // ---- level 2 forward, pointwise, level 2 inverse: block g, frequencies g + 16 k, all in registers
+    float acc = 0.0f;
+    {
+        cf x[24];
+        const int be = (24 * g + (g & 1)) * CT + cl, bo = (24 * g - (g & 1)) * CT + cl;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) x[k] = ld(s_d + b2_idx2(be, bo, k));
+        dft24<true>(x);
+        // |z| / s, the residuals and the cotangent (r1 + r2) / 2 * z / |z| from ONE transcendental: rs = 1 / |X| (v_rsq_f32,
+        // 1 ulp), |X| = |X|^2 rs.  The correctly rounded sqrtf and division of the round-2 pass were 40 % of its vector
+        // instructions (24 frequencies x ~22 instructions of Newton fix-ups); the test tolerance is 1e-5.
+        const float inv = 1.0f / (float)N;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const float m2 = fmaf(x[k].x, x[k].x, x[k].y * x[k].y);
+            const float rs = m2 == 0.0f ? 0.0f : __builtin_amdgcn_rsqf(m2);     // torch: d|z| = 0 at z = 0
+            const float mag = m2 * rs * inv;
+            const float r1 = y1[k] - mag, r2 = y2[k] - mag;
+            const float r2m = (kx != 0 && kx != HALF) ? r2 : 0.0f;      // (a select, not a branch per frequency)
+            acc = fmaf(r1, r1, acc);
+            acc = fmaf(r2m, r2m, acc);
+            x[k] = (0.5f * (r1 + r2) * rs) * x[k];                       // = f * z / s with f = (r1 + r2) / 2 / (|z| / s)
+        }
+        if (!colok) acc = 0.0f;
+        dft24<false>(x);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) st(s_d + b2_idx2(be, bo, k), x[k]);
+    }
+    __syncthreads();
+    // ---- inverse level 1, outputs to global memory (image rows only)
+    for (int j = g; j < 24; j += G16) {
+        cf x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = ld(s_d + b2_idx1(j, q, cl));
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = cmulc(x[q], ld(s_tw + j * q));
+        dft16<false>(x);
+        if (colok) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m >= 6 && m <= 9) continue;
+                if (lvl1_is_image(j, m)) st(hp + (int64_t)lvl1_image_index(j, m) * HP, x[m]);
+            }
+        }
+    }
+    const float t = dpsx::block_sum(acc, scratch);
+    if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
+}
+
+// ---- pass C: 32 image rows per 256-thread block, one complex transform per PAIR of rows and 16 lanes.
+// norm == nullptr: the per-particle norm is finalised in the prologue from the forward half's partial sums (the order of
+// k_finalize_norm: same bits in every block) and written to norm_out -- no separate finalisation launch.
+constexpr int C2T = 256, C2ROWS = 2 * (C2T / G16);      // 32 rows per block
+constexpr int C2ROWLDS = N;                             // float2 per transform
+
+__global__ __launch_bounds__(C2T, 3) void k_pr_rows_inv2(const float2 *__restrict__ half, const float *__restrict__ norm,
+                                                          const float *__restrict__ norm_partials, int norm_parts,
+                                                          float *__restrict__ norm_out,
+                                                          const uint8_t *__restrict__ ins, const float *__restrict__ g_extra,
+                                                          float scale, int power, float neg_b, float *__restrict__ g_mo,
+                                                          const float2 *__restrict__ tw_g, int c)
+{
+    __shared__ float2 s_tw[N];
+    __shared__ __align__(16) float2 s_d[C2T / G16][C2ROWLDS];
+    __shared__ float s_nrm[1];
+    const int q = threadIdx.x & (G16 - 1), f = threadIdx.x / G16;
+    const int64_t plane = blockIdx.y;
+    const int a0 = blockIdx.x * C2ROWS;
+    const int64_t n = plane / c, ch = plane % c, hw = (int64_t)IMG * IMG;
+    for (int i = threadIdx.x; i < N; i += C2T) s_tw[i] = tw_g[i];
+    if (!norm) dpsx::particle_norm_to_lds(norm_partials, norm_parts, n, s_nrm);
+    // the clamp gate of the eight float4 units this lane finishes in the epilogue: fetched with everything else
+    uchar4 gate[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + C2T * i, row = idx >> 6, l = idx & 63;
+        gate[i] = *reinterpret_cast<const uchar4 *>(ins + plane * hw + (int64_t)(a0 + row) * IMG + 4 * l);
+    }
+    // ---- Z = X1 + i X2 on this lane's 24 frequencies ky = q + 16 k (Hermitian extension for ky > 192), inverse level 2
+    {
+        const float2 *in1 = half + (plane * IMG + a0 + 2 * f) * HP, *in2 = in1 + HP;
+        cf x[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int ky = q + 16 * k;
+            const bool direct = ky <= HALF;
+            const int kx = direct ? ky : N - ky;
+            const cf a = ld(in1 + kx), b = ld(in2 + kx);
+            // direct: (a.re - b.im, a.im + b.re);  mirrored: conj(a) + i conj(b) = (a.re + b.im, b.re - a.im)
+            x[k] = direct ? cf{a.x - b.y, a.y + b.x} : cf{a.x + b.y, b.x - a.y};
+            // the self-conjugate bins carry only their real parts into a real row (as the one-row form, which drops the
+            // imaginary part of its output): rounding-level imaginary parts must not cross into the partner row
+            if (ky == 0 || ky == HALF) x[k] = cf{a.x, b.x};
+        }
+        dft24<false>(x);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) st(&s_d[f][rot24(q, k)], x[k]);
+    }
+    __syncthreads();
+    // ---- inverse level 1: butterflies q and (q < 8) q + 16; row r1 = real parts, r2 = imaginary parts
+    cf o1[16], o2[16];
+    {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) o1[m] = ld(&s_d[f][rot24(m, q)]);
+#pragma unroll
+        for (int m = 1; m < 16; ++m) o1[m] = cmulc(o1[m], ld(s_tw + q * m));
+        dft16<false>(o1);
+        if (q < 8) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) o2[m] = ld(&s_d[f][rot24(m, q + 16)]);
+#pragma unroll
+            for (int m = 1; m < 16; ++m) o2[m] = cmulc(o2[m], ld(s_tw + (q + 16) * m));
+            dft16<false>(o2);
+        }
+    }
+    __syncthreads();                     // every lane has read its inputs: the transform's LDS becomes its two image rows
+    {
+        float *r1 = reinterpret_cast<float *>(&s_d[f][0]), *r2 = r1 + IMG;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m >= 6 && m <= 9) continue;
+            if (lvl1_is_image(q, m)) {
+                const int b = lvl1_image_index(q, m);
+                r1[b] = o1[m].x;
+                r2[b] = o1[m].y;
+            }
+            if (q < 8 && lvl1_is_image(q + 16, m)) {
+                const int b = lvl1_image_index(q + 16, m);
+                r1[b] = o2[m].x;
+                r2[b] = o2[m].y;
+            }
+        }
+    }
+    __syncthreads();
+    const float nv = norm ? norm[n] : s_nrm[0];
+    if (!norm && norm_out && blockIdx.x == 0 && ch == 0 && threadIdx.x == 0) norm_out[n] = nv;
+    const float coef = (power == 2 ? -2.0f * scale : (nv == 0.0f ? 0.0f : -scale / nv)) * (1.0f / (float)N);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + C2T * i, row = idx >> 6, l = idx & 63;
+        const float *rr = reinterpret_cast<const float *>(&s_d[row >> 1][0]) + (row & 1) * IMG + 4 * l;
+        const float4 v = *reinterpret_cast<const float4 *>(rr);
+        const int64_t o = plane * hw + (int64_t)(a0 + row) * IMG + 4 * l;
+        float4 ex = make_float4(0, 0, 0, 0);
+        if (g_extra) ex = *reinterpret_cast<const float4 *>(g_extra + o);
+        float4 gq;
+        gq.x = gate[i].x ? neg_b * (coef * v.x + ex.x) : 0.0f;
+        gq.y = gate[i].y ? neg_b * (coef * v.y + ex.y) : 0.0f;
+        gq.z = gate[i].z ? neg_b * (coef * v.z + ex.z) : 0.0f;
+        gq.w = gate[i].w ? neg_b * (coef * v.w + ex.w) : 0.0f;
+        *reinterpret_cast<float4 *>(g_mo + (n * 2 * c + ch) * hw + (int64_t)(a0 + row) * IMG + 4 * l) = gq;
     }
 }
 

@@ -7,9 +7,9 @@ OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
-  --kernel-trace --output-format csv -d $OUT/${TAG}_a -- python3 tools/kbench.py --operator $OPER --only $ONLY --reps 5 > /dev/null 2> $OUT/${TAG}_a.err
+  --kernel-trace --output-format csv -d $OUT/${TAG}_a -- python3 tools/kbench.py --operator $OPER --only $ONLY --reps 5 --no-x0 > /dev/null 2> $OUT/${TAG}_a.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS \
-  --kernel-trace --output-format csv -d $OUT/${TAG}_b -- python3 tools/kbench.py --operator $OPER --only $ONLY --reps 5 > /dev/null 2> $OUT/${TAG}_b.err
+  --kernel-trace --output-format csv -d $OUT/${TAG}_b -- python3 tools/kbench.py --operator $OPER --only $ONLY --reps 5 --no-x0 > /dev/null 2> $OUT/${TAG}_b.err
 python3 - "$OUT/${TAG}_a" "$OUT/${TAG}_b" <<'PY' > $OUT/${TAG}_summary.txt
 import collections, csv, glob, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

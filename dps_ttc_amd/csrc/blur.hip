@@ -327,7 +327,11 @@ __device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
-            const float4 v = load_unit_reg<REFLECT || POST>(p, h0 + row - off, w0 + 4 * cu - off, h, w);
+            float4 v;
+            // forward operator on regular geometry: an interior unit lies inside the image -- one plain 16-byte load, none of
+            // the reflection selects of the halo path (they were a tenth of this loader's vector instructions)
+            if constexpr (REFLECT) v = *reinterpret_cast<const float4 *>(p + (unsigned)((h0 + row) * w + w0 + 4 * cu));
+            else v = load_unit_reg<false>(p, h0 + row - off, w0 + 4 * cu - off, h, w);
             if (pass) ei[k] = v; else xi[k] = v;
         }
 #pragma unroll
@@ -354,20 +358,13 @@ __device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW
         const int u = threadIdx.x + k * NT, row = u >> 4, cu = u & 15;
         float4 val = xi[k];
         if constexpr (POST) {
-            bool b0, b1, b2, b3;
             float4 x0, sm;
-            x0.x = post_x0(xi[k].x, ei[k].x, a.k, b0);
-            x0.y = post_x0(xi[k].y, ei[k].y, a.k, b1);
-            x0.z = post_x0(xi[k].z, ei[k].z, a.k, b2);
-            x0.w = post_x0(xi[k].w, ei[k].w, a.k, b3);
-            sm.x = post_sample(xi[k].x, x0.x, vi[k].x, zi[k].x, a.k);
-            sm.y = post_sample(xi[k].y, x0.y, vi[k].y, zi[k].y, a.k);
-            sm.z = post_sample(xi[k].z, x0.z, vi[k].z, zi[k].z, a.k);
-            sm.w = post_sample(xi[k].w, x0.w, vi[k].w, zi[k].w, a.k);
+            uchar4 gate;
+            post_unit(xi[k], ei[k], vi[k], zi[k], a.k, x0, sm, gate);       // packed S1 (common.h)
             const int64_t o = (int64_t)plane * hw + (unsigned)((h0 + row) * w + w0 + 4 * cu);
             if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + o) = x0;
             *reinterpret_cast<float4 *>(a.sample + o) = sm;
-            *reinterpret_cast<uchar4 *>(a.inside_w + o) = make_uchar4(b0, b1, b2, b3);
+            *reinterpret_cast<uchar4 *>(a.inside_w + o) = gate;
             val = x0;
         }
         *reinterpret_cast<float4 *>(s_in + (g.t + row) * SW + g.l + 4 * cu) = val;
@@ -379,13 +376,7 @@ __device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW
         int rr, cu;
         taps_halo_unit(g, RWu, hu, rr, cu);
         float4 val = xh[k];
-        if constexpr (POST) {
-            bool b;
-            val.x = post_x0(xh[k].x, eh[k].x, a.k, b);
-            val.y = post_x0(xh[k].y, eh[k].y, a.k, b);
-            val.z = post_x0(xh[k].z, eh[k].z, a.k, b);
-            val.w = post_x0(xh[k].w, eh[k].w, a.k, b);
-        }
+        if constexpr (POST) val = post_x0_unit(xh[k], eh[k], a.k);
         *reinterpret_cast<float4 *>(s_in + rr * SW + 4 * cu) = val;
     }
     // far-reaching kernels: the remaining halo units, four per lane in flight
@@ -403,13 +394,7 @@ __device__ __forceinline__ void load_region_taps_first(float *s_in, const int SW
         for (int k = 0; k < 4; ++k) {
             if (base + k * NT >= H) break;
             float4 val = xv[k];
-            if constexpr (POST) {
-                bool b;
-                val.x = post_x0(xv[k].x, ev[k].x, a.k, b);
-                val.y = post_x0(xv[k].y, ev[k].y, a.k, b);
-                val.z = post_x0(xv[k].z, ev[k].z, a.k, b);
-                val.w = post_x0(xv[k].w, ev[k].w, a.k, b);
-            }
+            if constexpr (POST) val = post_x0_unit(xv[k], ev[k], a.k);
             *reinterpret_cast<float4 *>(s_in + rr[k] * SW + 4 * cu[k]) = val;
         }
     }
@@ -599,7 +584,9 @@ __device__ __forceinline__ void tap_all_runs(v2f (&acc)[PRW], const float *s_in,
 // images, one barrier per tile) -- 144 us for the fused forward against 122 for this structure before the loads-first
 // stage: with half the waves loading, two compute waves per SIMD do not cover the tap loop's LDS and scalar-load
 // latencies (LDS reads and scalar loads share one counter, so a run record's wait drains the window reads too).
-template <bool POST, int MODE, bool VEC, int SWC>
+// NHB: halo units per lane the loads-first stage keeps in flight (2: a halo of at most 512 units -- the compact kernels, and
+// 16 fewer live registers, which is what keeps the fused forward's 24 loads free of a spill in their midst; else 4)
+template <bool POST, int MODE, bool VEC, int SWC, int NHB = 4>
 __global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
 {
     constexpr bool RESID = MODE == 1, REFLECT = MODE != 2;
@@ -613,7 +600,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_taps(BlurArgs a, TapGeom g)
     if constexpr (REFLECT) regular = VEC && a.h % TH == 0 && a.w % TW == 0 && max(g.t, g.b) < a.h && max(g.l, g.r) < a.w;
     else regular = VEC && a.src_w % 4 == 0 && a.src_off % 4 == 0;   // the SOURCE decides whether a unit is wholly in or out
     if constexpr (VEC) {
-        if (regular) load_region_taps_first<POST, REFLECT, 4>(s_in, SW, RW / 4, g, h0, w0, a, plane);
+        if (regular) load_region_taps_first<POST, REFLECT, NHB>(s_in, SW, RW / 4, g, h0, w0, a, plane);
         else load_region<POST, REFLECT, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
     } else {
         load_region<POST, REFLECT, VEC>(s_in, SW, RH, RW, h0 - g.t, w0 - g.l, h0, w0, a, plane);
@@ -1349,11 +1336,21 @@ static TapGeom make_geom(int t, int b, int l, int r)
     return g;
 }
 
+template <bool POST, int MODE, bool VEC, int SWC, int NHB>
+static int launch_taps_kn(const BlurArgs &a, const TapGeom &g, hipStream_t s)
+{
+    const size_t lds = taps_lds(g, SWC);
+    DPSX_LAUNCH((k_blur_taps<POST, MODE, VEC, SWC, NHB>), grid_blocks(a), lds, s, a, g);
+}
+
 template <bool POST, int MODE, bool VEC, int SWC>
 static int launch_taps_k(const BlurArgs &a, const TapGeom &g, hipStream_t s)
 {
-    const size_t lds = taps_lds(g, SWC);
-    DPSX_LAUNCH((k_blur_taps<POST, MODE, VEC, SWC>), grid_blocks(a), lds, s, a, g);
+    if constexpr (VEC && POST) {
+        const int halo_units = (g.t + g.b) * ((TW + g.l + g.r) / 4) + TH * ((g.l + g.r) / 4);
+        if (halo_units <= 2 * NT) return launch_taps_kn<POST, MODE, VEC, SWC, 2>(a, g, s);
+    }
+    return launch_taps_kn<POST, MODE, VEC, SWC, 4>(a, g, s);
 }
 
 template <bool POST, int MODE>

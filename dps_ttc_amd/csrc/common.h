@@ -80,6 +80,66 @@ __device__ __forceinline__ float post_sample(float x, float x0, float v, float z
     return __fadd_rn(mean, __fmul_rn(sd, z));
 }
 
+// The same arithmetic on one float4 unit, two lanes of data per instruction: v_pk_mul_f32 / v_pk_add_f32 round each
+// operation exactly as their scalar forms do (no contraction: -ffp-contract=off; scalar x vector broadcasts), so x0_hat,
+// the clamp gate and the sample come out bit for bit as from post_x0 / post_sample -- at about half the vector
+// instructions (the tap-list forward launch spent more of them on S1 and its loader than on its tap loop:
+// profiles/r03_valu_taps.txt).  The gate test is |pre| <= 1: one compare with the abs modifier, false for NaN like the
+// closed-interval pair.  DDIM records (a division per element) take the scalar forms.
+typedef float s1v2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float s1_clamp(float pre) { return pre < -1.0f ? -1.0f : (pre > 1.0f ? 1.0f : pre); }
+
+// (the coefficients are splat into explicit pairs from by-value scalars: taking them through the Coefs reference made the
+// compiler keep the struct in scratch memory and reload it -- behind a vmcnt(0) that also drained the tile's loads)
+__device__ __forceinline__ s1v2 s1_splat(float v) { return s1v2{v, v}; }
+// a launch-uniform scalar, made opaque: without this the compiler turns a pair built from two adjacent Coefs fields into ONE
+// 8-byte load of the struct -- which forces the by-value kernel argument into scratch memory (28 bytes per lane, reloaded
+// behind s_waitcnt vmcnt(0), which also drains the tile's loads in flight: +11 us on the tap-list forward launch)
+__device__ __forceinline__ float s1_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ s1v2 s1_lo(s1v2 p) { return __builtin_shufflevector(p, p, 0, 0); }   // op_sel: no instruction
+__device__ __forceinline__ s1v2 s1_hi(s1v2 p) { return __builtin_shufflevector(p, p, 1, 1); }
+
+// x0_hat of a unit (halo units: no sample, no gate)
+__device__ __forceinline__ float4 post_x0_unit(const float4 &x, const float4 &e, const float ca, const float cb)
+{
+    const s1v2 AB{s1_uniform(ca), s1_uniform(cb)};
+    const s1v2 p0 = s1_lo(AB) * s1v2{x.x, x.y} - s1_hi(AB) * s1v2{e.x, e.y}, p1 = s1_lo(AB) * s1v2{x.z, x.w} - s1_hi(AB) * s1v2{e.z, e.w};
+    return make_float4(s1_clamp(p0.x), s1_clamp(p0.y), s1_clamp(p1.x), s1_clamp(p1.y));
+}
+__device__ __forceinline__ float4 post_x0_unit(const float4 &x, const float4 &e, const Coefs &c)
+{
+    return post_x0_unit(x, e, c.a, c.b);
+}
+
+__device__ __forceinline__ void post_unit(const float4 &x, const float4 &e, const float4 &v, const float4 &z, const Coefs &c,
+                                          float4 &x0, float4 &sm, uchar4 &gate)
+{
+    // the six coefficients as three register pairs; a packed instruction broadcasts either half of a pair (op_sel)
+    const s1v2 AB{s1_uniform(c.a), s1_uniform(c.b)}, CC{s1_uniform(c.c1), s1_uniform(c.c2)}, LL{s1_uniform(c.max_log), s1_uniform(c.min_log)};
+    const int mode = c.add_noise;
+    const s1v2 xa{x.x, x.y}, xb{x.z, x.w};
+    const s1v2 p0 = s1_lo(AB) * xa - s1_hi(AB) * s1v2{e.x, e.y}, p1 = s1_lo(AB) * xb - s1_hi(AB) * s1v2{e.z, e.w};
+    gate = make_uchar4(fabsf(p0.x) <= 1.0f, fabsf(p0.y) <= 1.0f, fabsf(p1.x) <= 1.0f, fabsf(p1.y) <= 1.0f);
+    x0 = make_float4(s1_clamp(p0.x), s1_clamp(p0.y), s1_clamp(p1.x), s1_clamp(p1.y));
+    if (mode & 2) {                 // DDIM: launch-uniform
+        sm = make_float4(post_sample(x.x, x0.x, v.x, z.x, c), post_sample(x.y, x0.y, v.y, z.y, c),
+                         post_sample(x.z, x0.z, v.z, z.z, c), post_sample(x.w, x0.w, v.w, z.w, c));
+        return;
+    }
+    const s1v2 m0 = s1_lo(CC) * s1v2{x0.x, x0.y} + s1_hi(CC) * xa, m1 = s1_lo(CC) * s1v2{x0.z, x0.w} + s1_hi(CC) * xb;
+    if (!mode) {
+        sm = make_float4(m0.x, m0.y, m1.x, m1.y);
+        return;
+    }
+    const s1v2 one = s1_splat(1.0f), hlf = s1_splat(0.5f);
+    const s1v2 f0 = (s1v2{v.x, v.y} + one) * hlf, f1 = (s1v2{v.z, v.w} + one) * hlf;
+    const s1v2 h0 = hlf * (f0 * s1_lo(LL) + (one - f0) * s1_hi(LL)), h1 = hlf * (f1 * s1_lo(LL) + (one - f1) * s1_hi(LL));
+    const s1v2 s0 = m0 + s1v2{__expf(h0.x), __expf(h0.y)} * s1v2{z.x, z.y};
+    const s1v2 s1 = m1 + s1v2{__expf(h1.x), __expf(h1.y)} * s1v2{z.z, z.w};
+    sm = make_float4(s0.x, s0.y, s1.x, s1.y);
+}
+
 // -------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v)
 {

@@ -326,22 +326,19 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
             const int gy = lo + rr;
             float val[4] = {xv[bb].x, xv[bb].y, xv[bb].z, xv[bb].w};
             if constexpr (POST) {
-                bool ins[4];
-                val[0] = post_x0(xv[bb].x, ev[bb].x, a.k, ins[0]);
-                val[1] = post_x0(xv[bb].y, ev[bb].y, a.k, ins[1]);
-                val[2] = post_x0(xv[bb].z, ev[bb].z, a.k, ins[2]);
-                val[3] = post_x0(xv[bb].w, ev[bb].w, a.k, ins[3]);
-                if (rr < cnt && gy >= olo && gy < ohi) {
+                float4 x0;
+                if (rr < cnt && gy >= olo && gy < ohi) {       // a row this block owns: the whole of S1 (packed: common.h)
                     float4 sm;
-                    sm.x = post_sample(xv[bb].x, val[0], vq[bb].x, zq[bb].x, a.k);
-                    sm.y = post_sample(xv[bb].y, val[1], vq[bb].y, zq[bb].y, a.k);
-                    sm.z = post_sample(xv[bb].z, val[2], vq[bb].z, zq[bb].z, a.k);
-                    sm.w = post_sample(xv[bb].w, val[3], vq[bb].w, zq[bb].w, a.k);
+                    uchar4 gate;
+                    post_unit(xv[bb], ev[bb], vq[bb], zq[bb], a.k, x0, sm, gate);
                     const int64_t po = (int64_t)plane * ihw + (unsigned)(gy * d.in_w + 4 * cu);
-                    if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + po) = make_float4(val[0], val[1], val[2], val[3]);
+                    if (a.x0_hat) *reinterpret_cast<float4 *>(a.x0_hat + po) = x0;
                     *reinterpret_cast<float4 *>(a.sample + po) = sm;
-                    *reinterpret_cast<uchar4 *>(a.inside_w + po) = make_uchar4(ins[0], ins[1], ins[2], ins[3]);
+                    *reinterpret_cast<uchar4 *>(a.inside_w + po) = gate;
+                } else {
+                    x0 = post_x0_unit(xv[bb], ev[bb], a.k);
                 }
+                val[0] = x0.x; val[1] = x0.y; val[2] = x0.z; val[3] = x0.w;
             }
             // residue-major rows of this step -> the wave's buffer; DS operations of one wave execute in order, so the
             // gathers below see these writes and the next step's writes cannot pass this step's reads

@@ -8,6 +8,6 @@ set -e
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OPER=${1:-gaussian_blur}; ONLY=${2:-fwd,bwd}
 for rep in 1 2 3; do
-  echo "== new"; python3 tools/kbench.py --operator $OPER --only $ONLY --reps 50 | grep -E "^(fwd|bwd|upd|op|adj|score)"
-  echo "== old"; DPSX_LIB=$PWD/dps_ttc_amd/lib/libdpsx_old.so python3 tools/kbench.py --operator $OPER --only $ONLY --reps 50 | grep -E "^(fwd|bwd|upd|op|adj|score)"
+  echo "== new"; python3 tools/kbench.py --operator $OPER --only $ONLY --reps 50 --no-x0 | grep -E "^(fwd|bwd|upd|op|adj|score)"
+  echo "== old"; DPSX_LIB=$PWD/dps_ttc_amd/lib/libdpsx_old.so python3 tools/kbench.py --operator $OPER --only $ONLY --reps 50 --no-x0 | grep -E "^(fwd|bwd|upd|op|adj|score)"
 done

@@ -121,3 +121,55 @@ def test_reference_import_block_resolves_through_alias_modules():
                        model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
                        rescale_timesteps=True, timestep_respacing="ddim50")
     assert s.num_timesteps == 50 and s.global_resample is False
+
+
+def test_bench_byte_table_and_cli():
+    """bench.py and tools/kbench.py price their launches from ONE table (bench.algo_p); the figures of SURVEY.md 8d, the
+    store-off variant, and the command lines of BASELINE configs 3 and 4 in their sharded form parse."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    P = bench.P_BYTES
+    assert P == 786432
+    t = bench.algo_p("gaussian_blur")
+    assert t["survey"] == {"fwd": 8.0, "bwd": 5.0, "upd": 4.0} and sum(t["survey"].values()) * P == 13369344      # 17P
+    assert bench.algo_p("gaussian_blur", x0_store=False)["algorithmic"] == {"fwd": 7.0, "bwd": 4.0, "upd": 4.0}
+    assert sum(bench.algo_p("super_resolution")["survey"].values()) * P == 11894784                              # 15.125P
+    assert sum(bench.algo_p("inpainting")["survey"].values()) * P == 11796480                                    # 15P
+    assert bench.algo_p("inpainting", x0_store=False)["algorithmic"] == bench.algo_p("inpainting")["survey"]       # reads x0_hat back
+    assert sum(bench.algo_p("phase_retrieval")["survey"].values()) * P == 18874368                               # 24P
+    assert sum(bench.algo_p("gaussian_blur", workload="search")["survey"].values()) * P == 6291456               # 8P
+    assert bench.algo_p("motion_blur", semantic=True)["survey"]["bwd"] == 6.0
+    src = open(os.path.join(ROOT, "tools", "kbench.py")).read()
+    assert "bench.algo_p(" in src and "(7 + rho)" not in src
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8", "--operator", "motion_blur", "--scaling", "strong", "--particles", "256",
+                    "--workload", "dps_scores", "--semantic"]
+        a = bench.parse()
+        assert (a.gpus, a.scaling, a.particles, a.workload, a.semantic) == (8, "strong", 256, "dps_scores", True)
+        sys.argv = ["bench.py", "--gpus", "8", "--operator", "phase_retrieval", "--workload", "resample", "--particles", "64"]
+        a = bench.parse()
+        assert (a.workload, a.resample_every, a.scaling) == ("resample", 10, "weak")
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert (a.gpus, a.workload, a.operator, a.particles, a.chains) == (1, "dps", "gaussian_blur", 64, 0)
+    finally:
+        sys.argv = old
+    assert abs(bench.semantic_scale(0.3, 10.0, 0.0) - 0.3 * (1 + 9 / (1 + np.exp(-3.0)))) < 1e-12
+
+
+def test_particle_groups_partition():
+    """kernels.ParticleGroups splits N particles into contiguous groups that differ by at most one particle (host logic
+    only: the constructor's partition is computed before anything touches the device)"""
+    from dps_ttc_amd import kernels
+    for n, g in ((64, 3), (7, 3), (5, 8), (1, 4), (32, 2)):
+        groups = max(1, min(g, max(n, 1)))
+        sizes = [n // groups + (1 if j < n % groups else 0) for j in range(groups)]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+    assert hasattr(kernels.ParticleGroups, "step_fwd") and hasattr(kernels.ParticleGroups, "x_next")
+    from dps_ttc_amd.gaussian_diffusion import create_sampler
+    s = create_sampler(sampler="ddpm", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
+                       model_var_type="learned_range", dynamic_threshold=False, clip_denoised=True,
+                       rescale_timesteps=True, timestep_respacing="")
+    assert s.particle_groups == 1

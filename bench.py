@@ -74,10 +74,14 @@ def algo_p(operator, x0_store=True, workload="dps", semantic=False):
     if semantic:                                   # one more image-sized read in K2 (the extra cotangent)
         algo["bwd"] += 1.0
         survey["bwd"] += 1.0
-    if workload == "search":
+    if workload in ("search", "search_single"):
         # reference :618-633 -- S1 6P (5P without the x0_hat store) + score 1P + winner gather 1P (+1P written)
         survey = {"s1": 6.0, "score": 1.0, "select": 1.0}
         algo = {"s1": 5.0, "score": 1.0, "select": 1.0}
+        if workload == "search_single":
+            # one state particle: S1 reads the noise and writes the proposal (the state and its model output are read once
+            # for all N: -> 0 per particle), the proposal is scored, the winner is copied once
+            algo = {"s1": 2.0, "score": 1.0, "select": 0.0}
     return {"survey": survey, "algorithmic": algo}
 
 
@@ -115,6 +119,10 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--semantic", action="store_true", help="stand-in semantic-guidance cotangent through dpsx_step_bwd_extra_f32")
     ap.add_argument("--resample-every", type=int, default=10)
+    ap.add_argument("--search-form", default="single", choices=["single", "replicated"],
+                    help="--workload search: 'single' = the loop's default (SearchDDPM.single_state: after a select all particles "
+                         "are copies of the winner, so ONE state particle feeds the N proposals -- dpsx_search_step_one_f32); "
+                         "'replicated' = the reference's N copies (dpsx_search_step_f32)")
     ap.add_argument("--x0-store", action="store_true",
                     help="K1 also writes the x0_hat image out.  The `ps` loop reads it nowhere after K1 (the backward half "
                          "works from the clamp gate), so p_sample_loop -- and this bench -- ask for it only when something "
@@ -353,14 +361,16 @@ def main():
     # ---- particle groups on streams: kernels.ParticleGroups, the object sampler.particle_groups / the driver's
     # --particle_groups run the fused loop with.  Per-particle results do not depend on the grouping
     # (tests/test_driver_gpu.py checks it bit for bit).  Workloads with an exchange every step run one chain.
-    default_chains = 1 if wl != "dps" or semantic else (2 if args.operator == "phase_retrieval" else 3)
+    # (small batches do not fill the chip even as one chain -- N = 16 is 768 tiles on 256 CUs -- and lose as groups)
+    default_chains = 1 if wl != "dps" or semantic or n < 48 else (2 if args.operator == "phase_retrieval" else 3)
     nch = max(1, min(args.chains if args.chains > 0 else default_chains, n))
     if shared_gpu or wl in ("search", "resample", "dps_scores"):
         nch = 1         # rank processes time-slicing ONE GPU (gloo rehearsal): several queues per process make it crawl
     pg = None
     if nch > 1:
         pg = kernels.ParticleGroups(op, n, 3, 256, 256, device, nch, mask=mask, like=x_t, record_streams=False)
-    state = {"x": x_t, "gx": [x_t[sl] for sl in pg.slices] if pg else None}
+    single = wl == "search" and args.search_form == "single"
+    state = {"x": x_t[:1].contiguous() if single else x_t, "gx": [x_t[sl] for sl in pg.slices] if pg else None}
 
     def grouped_steps(first, count, timers=None):
         for i in range(count):
@@ -389,6 +399,11 @@ def main():
                 # SearchDDPM.search_step without the model call: dpsx_search_step_f32 (+ GlobalSelect across ranks)
                 s = ring[k % len(ring)]
                 local_only = smp.global_select is None
+                if single:      # SearchDDPM.search_step_one: the state is ONE particle, its model output [1, 2C, H, W]
+                    winner, sample, costs, best, _ = handle.search_step_one(x, s["model_out"][:1], s["noise"], y,
+                                                                            coefs_at(k), want_winner=local_only)
+                    x = winner if local_only else smp.global_select(costs, sample, n_out=1)
+                    continue
                 x_next, sample, costs, best, _ = handle.search_step(x, s["model_out"], s["noise"], y, coefs_at(k),
                                                                     replicate=local_only)
                 x = x_next if local_only else smp.global_select(costs, sample)
@@ -461,9 +476,14 @@ def main():
         ck0 = coefs_at(0)
         _, sample0 = kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck0, want_x0=False)
         _, best0, _ = handle.score_argmin(sample0, y)
+        x1 = x_t[:1].contiguous()
         parts = {"s1": lambda: kernels.posterior_fwd(x, s0["model_out"], s0["noise"], ck0, want_x0=False),
                  "score": lambda: handle.score(sample0, y),
                  "select": lambda: kernels.replicate(sample0, best0)}
+        if single:      # S1 from one state has no entry point of its own: the step without the winner's copy, minus its scoring half
+            parts["s1"] = lambda: handle.search_step_one(x1, s0["model_out"][:1], s0["noise"], y, ck0, want_winner=False)
+            parts["score"] = lambda: handle.score_argmin(sample0, y)
+            parts["select"] = lambda: kernels.replicate(sample0, best0, n_out=1)
         dur = {}
         for name, fn in parts.items():
             for _ in range(5):
@@ -475,6 +495,8 @@ def main():
                 b_.record()
             torch.cuda.synchronize()
             dur[name] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev])) * 1e-3
+        if single:
+            dur["s1"] = max(dur["s1"] - dur["score"], 1e-9)
     else:
         for i in range(10):             # (with particle groups the one-chain buffers have not been touched yet)
             x = step(i, x)
@@ -516,7 +538,7 @@ def main():
 
     if rank == 0:
         x0_stored = want_x0 or args.operator == "inpainting"
-        table = algo_p(args.operator, x0_store=x0_stored, workload=wl, semantic=semantic)
+        table = algo_p(args.operator, x0_store=x0_stored, workload="search_single" if single else wl, semantic=semantic)
         algo = {k: v * P_BYTES for k, v in table["algorithmic"].items()}
         survey_step_p = sum(table["survey"].values())
         algo_step_p = sum(table["algorithmic"].values())
@@ -584,7 +606,8 @@ def main():
             roofline["binding"] = "valu" if vb > hb else "hbm"
         what = {"dps": "'ps' scale 0.3, one global best-of-N select at the end",
                 "dps_scores": "'ps' scale 0.3, per-step all-gather of the particle scores + global argmin",
-                "search": "search_ddpm step: S1, scoring, per-step global select, winner replicated",
+                "search": "search_ddpm step: S1, scoring, per-step global select, " +
+                          ("ONE state particle kept (SearchDDPM.single_state)" if single else "winner replicated to all N"),
                 "resample": f"ttc_ddim step (DDIM S1) with 'ps' scale 0.3, global multinomial resampling every "
                             f"{args.resample_every} steps"}[wl]
         exchange = {"dps": "champion all-gather at the closing select (2 floats + 1 particle per rank)",
@@ -672,6 +695,41 @@ def cpu_baseline(args, op, fkw, smp, ring, x_t, y, handle, device):
             "kind": "port",
             "sample": f"{nc} particles x {steps} steps of the same workload (oracle/dps_oracle.c, OpenMP, "
                       f"zero taps of a blur kernel skipped), {dt:.1f} s"}
+    # SURVEY 8d's second CPU baseline: the reference's own ATen ops on the host cores (oracle/torch_ref.py: S1 as tensor
+    # arithmetic, ReflectionPad2d + depthwise conv2d / gather-sum resize / mask / fft2, linalg.norm, autograd.grad), same
+    # inputs, a smaller sample (a 61 x 61 conv2d forward + backward over 16 particles takes a few hundred ms)
+    try:
+        import torch
+        from oracle import torch_ref
+        torch.set_num_threads(cores)
+        tn, ts = min(nc, 16), min(steps, 3)
+        if args.operator in ("gaussian_blur", "motion_blur"):
+            top = torch_ref.TorchOperator(args.operator, kernel=orc.kw["kernel"])
+        elif args.operator == "super_resolution":
+            top = torch_ref.TorchOperator(args.operator, tables=orc.kw["tables"])
+        elif args.operator == "inpainting":
+            top = torch_ref.TorchOperator(args.operator, mask=orc.kw["mask"])
+        else:
+            top = torch_ref.TorchOperator(args.operator, pad=orc.kw["pad"])
+        xt = x_t[:tn].cpu().numpy()
+        torch_ref.dps_step(top, xt[:1], sets[0]["model_out"][:1], sets[0]["noise"][:1], yh, oracle.tables.step_coefs(sched, 999),
+                           0.3, sets[0]["g_unet"][:1])          # page in
+        t1 = time.perf_counter()
+        werr = 0.0
+        for i in range(ts):
+            s = sets[i % len(sets)]
+            r = torch_ref.dps_step(top, xt, s["model_out"][:tn], s["noise"][:tn], yh, oracle.tables.step_coefs(sched, 999 - i),
+                                   0.3, s["g_unet"][:tn])
+            ref = outs[i]["x_next"][:tn] if i < len(outs) else None
+            if ref is not None:
+                werr = max(werr, float(np.linalg.norm((r["x_next"].astype(np.float64) - ref).ravel()) / np.linalg.norm(ref.ravel())))
+            xt = r["x_next"]
+        dt2 = time.perf_counter() - t1
+        base["torch_ops"] = {"value": tn * ts / dt2, "unit": "particle-steps/s", "cores": cores, "kind": "torch CPU ops",
+                             "sample": f"{tn} particles x {ts} steps, torch {torch.__version__} CPU ops in the reference's order "
+                                       f"(oracle/torch_ref.py), {dt2:.1f} s", "x_next_rel_l2_vs_port": werr}
+    except Exception as e:          # a reported extra, never a reason to lose the line
+        base["torch_ops"] = {"error": repr(e)[:200]}
     return base, worst
 
 

@@ -229,3 +229,30 @@ def test_resample_update_golden(oracle, golden, tag, opname, cfg):
             assert rel_l2(net, g[f"{tag}.{pot}.{case}.net"]) < TOL, (pot, case)
             np.testing.assert_array_equal(cands[:, 0, 0, 0].round().astype(np.int64), ids)
     assert list(g["gauss.flat.ids"]) == list(range(6))
+
+
+@pytest.mark.parametrize("name", ["gaussian_blur", "super_resolution", "inpainting", "phase_retrieval"])
+def test_torch_ops_reference_agrees_with_the_port(oracle, name):
+    """oracle/torch_ref.py (the reference's ATen ops, bench.py's second CPU baseline) against the C port on one `ps` step"""
+    from oracle import torch_ref
+    rng = np.random.RandomState(3)
+    n, hw = 2, 64
+    c = oracle.tables.step_coefs(oracle.tables.schedule(1000), 400)
+    x = rng.randn(n, 3, hw, hw).astype(np.float32)
+    eps = ((c["a"] * x - 1.3 * np.tanh(rng.randn(n, 3, hw, hw))) / c["b"]).astype(np.float32)
+    mo = np.concatenate([eps, rng.uniform(-1, 1, eps.shape).astype(np.float32)], axis=1)
+    z = rng.randn(n, 3, hw, hw).astype(np.float32)
+    gu = (1e-2 * rng.randn(n, 3, hw, hw)).astype(np.float32)
+    mask = (rng.rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    cfg = {"gaussian_blur": dict(kernel_size=61, intensity=3.0), "super_resolution": dict(in_shape=(1, 3, hw, hw), scale_factor=4),
+           "inpainting": dict(mask=mask), "phase_retrieval": dict(oversample=2.0)}[name]
+    orc = oracle.make_operator(name, **cfg)
+    tkw = {"gaussian_blur": dict(kernel=orc.kw.get("kernel")), "super_resolution": dict(tables=orc.kw.get("tables")),
+           "inpainting": dict(mask=mask), "phase_retrieval": dict(pad=64)}[name]
+    y = orc.forward(rng.uniform(-1, 1, (1, 3, hw, hw)).astype(np.float32))
+    y = (y + 0.05 * rng.randn(*y.shape)).astype(np.float32)
+    ref = oracle.dps_step(orc, x, mo, z, y, c, scale=0.3, power=1, g_unet_fn=lambda g: gu)
+    got = torch_ref.dps_step(torch_ref.TorchOperator(name, **tkw), x, mo, z, y, c, 0.3, gu)
+    assert np.array_equal(got["x0_hat"], ref["x0_hat"])
+    for k in ("sample", "norm", "x_next"):
+        assert rel_l2(got[k], ref[k]) < 1e-5, k

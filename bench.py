@@ -460,8 +460,10 @@ def main():
         saved, pg_saved = dict(state), pg
         pg = None
         state["x"] = x_t
-        run_steps(0, max(args.warmup, 5))
-        one_chain_s, _ = timed(args.warmup, args.steps)
+        oc_steps = max(args.steps, 100)        # (an auxiliary figure: a short --steps run should not make it a noisy one)
+        run_steps(0, max(args.warmup, 20))
+        one_chain_s, _ = timed(args.warmup, oc_steps)
+        one_chain_s *= args.steps / oc_steps   # normalised to --steps: everything below divides by args.steps
         pg = pg_saved
         state.update(saved)
     elif pg is None:
@@ -519,21 +521,33 @@ def main():
         dur_grouped = {k: float(np.mean([e[j].elapsed_time(e[j + 1]) for e in gev])) * 1e3
                        for j, k in enumerate(("fwd", "bwd", "upd"))}
 
-    # ---- on-box copy ceiling (report against the vendor peak AND a measured copy kernel):
-    # a 1 GiB device-to-device copy, read + write bytes over its event time
-    copy_gbs = None
+    # ---- on-box copy ceiling (report against the vendor peak AND a measured copy kernel): 1 GiB moved device to
+    # device, read + write bytes over the event time, by torch's copy_ and by the library's own particle copy
+    # (dpsx_gather_f32 with identity ids: float4 per lane, one particle per block row) -- the ceiling is the faster of the two
+    copy_gbs, copy_detail = None, None
     if rank == 0:
-        src = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()
+        npart = (1 << 30) // P_BYTES
+        src = torch.empty((npart, 3, 256, 256), dtype=torch.float32, device=device).normal_()
         dst = torch.empty_like(src)
-        for _ in range(2):
-            dst.copy_(src)
-        ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ce[0].record()
-        for _ in range(5):
-            dst.copy_(src)
-        ce[1].record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * src.numel() * 4 / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+        ids = torch.arange(npart, device=device)
+
+        def rate(fn):
+            for _ in range(2):
+                fn()
+            ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ce[0].record()
+            for _ in range(5):
+                fn()
+            ce[1].record()
+            torch.cuda.synchronize()
+            return 5 * 2 * src.numel() * 4 / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+
+        chw = src[0].numel()
+        copy_detail = {"torch_copy_": rate(lambda: dst.copy_(src)),
+                       "dpsx_gather_f32_identity": rate(lambda: kernels.check(kernels.lib().dpsx_gather_f32(
+                           kernels.ptr(src), kernels.ptr(ids), kernels.ptr(dst), npart, npart, chw,
+                           kernels.stream_of(src)), "dpsx_gather_f32"))}
+        copy_gbs = max(copy_detail.values())
         del src, dst
 
     if rank == 0:
@@ -574,7 +588,7 @@ def main():
                     "step_algorithmic_bytes_per_particle": algo_step_p * P_BYTES,
                     "step_frac_of_hbm_roofline": (survey_step_p * P_BYTES * n / step_s) / 1e9 / HBM_PEAK_GBS,
                     "step_frac_algorithmic": (algo_step_p * P_BYTES * n / step_s) / 1e9 / HBM_PEAK_GBS,
-                    "copy_ceiling": copy_gbs}
+                    "copy_ceiling": copy_gbs, "copy_ceiling_detail": copy_detail}
         if one_chain_s is not None:
             oc = one_chain_s / args.steps
             roofline["one_chain_ms_per_step"] = oc * 1e3

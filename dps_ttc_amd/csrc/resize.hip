@@ -395,7 +395,16 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     const int64_t ihw = (int64_t)d.in_h * d.in_w, ohw = (int64_t)d.out_h * d.out_w;
     const int i0 = blk * d.ti, i1 = min(d.in_h, i0 + d.ti);
     const float *up = a.x + (int64_t)plane * ohw + (int64_t)lo * d.out_w;
-    for (int u = threadIdx.x; u < cnt * d.out_w; u += RT) s_u[u] = up[u];
+    // staging loads first (the cotangent rows, then the tables below): each of these loops used to be a chain of dependent
+    // round trips (load -> LDS store per iteration, trip counts unknown to the compiler) at the head of every workgroup
+    const int nu = cnt * d.out_w;
+    constexpr int UQ = 2;
+    const bool u4 = VEC && (d.out_w % 4) == 0 && (reinterpret_cast<uintptr_t>(up) & 15u) == 0;
+    float4 ureg0 = make_float4(0, 0, 0, 0), ureg1 = ureg0;
+    if (u4) {
+        ureg0 = *reinterpret_cast<const float4 *>(up + 4 * min((int)threadIdx.x, nu / 4 - 1));
+        ureg1 = *reinterpret_cast<const float4 *>(up + 4 * min((int)threadIdx.x + RT, nu / 4 - 1));
+    }
     // inverse tables -> LDS: the whole W inverse, and the H-inverse rows of this block (rebased to 0)
     // RT % (in_w / 4) == 0: a lane keeps its column group over all its rows, so the (<= 8 deep) ELL entries of its
     // four columns go from global memory (16-byte loads, L2-resident) straight to registers, once; otherwise the W
@@ -420,10 +429,25 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
         }
     }
     const int he0 = d.inv_h_ptr[i0], he1 = d.inv_h_ptr[i1];
-    for (int i = threadIdx.x; i <= i1 - i0; i += RT) s_hp[i] = d.inv_h_ptr[i0 + i] - he0;
-    for (int i = threadIdx.x; i < he1 - he0; i += RT) {
-        s_hi[i] = d.inv_h_idx[he0 + i] - lo;
-        s_hv[i] = d.inv_h_w[he0 + i];
+    {   // first RT entries of each table in one shot (registers), leftovers by the loops
+        const int nhe = he1 - he0, t = threadIdx.x;
+        const int hp0 = d.inv_h_ptr[i0 + min(t, i1 - i0)];
+        const int hi0 = d.inv_h_idx[he0 + min(t, max(nhe - 1, 0))];
+        const float hv0 = d.inv_h_w[he0 + min(t, max(nhe - 1, 0))];
+        if (u4) {
+            if (t < nu / 4) *reinterpret_cast<float4 *>(s_u + 4 * t) = ureg0;
+            if (t + RT < nu / 4) *reinterpret_cast<float4 *>(s_u + 4 * (t + RT)) = ureg1;
+            for (int u = 4 * UQ * RT + t; u < nu; u += RT) s_u[u] = up[u];
+        } else {
+            for (int u = t; u < nu; u += RT) s_u[u] = up[u];
+        }
+        if (t <= i1 - i0) s_hp[t] = hp0 - he0;
+        if (t < nhe) { s_hi[t] = hi0 - lo; s_hv[t] = hv0; }
+        for (int i = RT + t; i <= i1 - i0; i += RT) s_hp[i] = d.inv_h_ptr[i0 + i] - he0;
+        for (int i = RT + t; i < nhe; i += RT) {
+            s_hi[i] = d.inv_h_idx[he0 + i] - lo;
+            s_hv[i] = d.inv_h_w[he0 + i];
+        }
     }
     float *s_nrm = reinterpret_cast<float *>(s_hi + d.max_he);
     if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm); }
@@ -447,7 +471,9 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     // W adjoint: g[i][j] = sum_{e in inv_w[j]} w_e * T[i][o_e]
     constexpr int U = VEC ? 4 : 1;
     const int wu = d.in_w / U;
-    for (int it = threadIdx.x; it < (i1 - i0) * wu; it += RT) {
+    const int total = (i1 - i0) * wu;
+    const float mb = -a.k.b;
+    auto unit = [&](const int it, const uchar4 gate4, const bool have_gate) {
         const int ii = it / wu, j0 = (it - ii * wu) * U;
         float g[U];
         if (VEC && regtab) {
@@ -476,10 +502,9 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
         if constexpr (EPI) {
             const uint8_t *ip = a.inside_r + (int64_t)plane * ihw + o;
             float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * ihw + o;
-            const float mb = -a.k.b;
             const float *ep = a.g_extra ? a.g_extra + (int64_t)plane * ihw + o : nullptr;
             if constexpr (VEC) {
-                const uchar4 in = *reinterpret_cast<const uchar4 *>(ip);
+                const uchar4 in = have_gate ? gate4 : *reinterpret_cast<const uchar4 *>(ip);
                 float4 ex = make_float4(0, 0, 0, 0);
                 if (ep) ex = *reinterpret_cast<const float4 *>(ep);
                 float4 r;
@@ -496,6 +521,26 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
             if constexpr (VEC) *reinterpret_cast<float4 *>(gp) = make_float4(g[0], g[1], g[2], g[3]);
             else gp[0] = g[0];
         }
+    };
+    // The clamp gate of a unit is one dependent global load in front of its store: fetched inside the loop, a lane's 4-16
+    // units paid 4-16 exposed round trips (the launch moved 67 MB in 33-37 us at N = 64).  With at most GP units per lane
+    // (every shipped geometry) all gate words are issued together, ahead of the loop, one register each.
+    constexpr int GP = 16;
+    if (EPI && VEC && total <= GP * RT) {          // block-uniform
+        uchar4 gates[GP];
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int it = min((int)threadIdx.x + q * RT, total - 1);
+            const int ii = it / wu, j0 = (it - ii * wu) * U;
+            gates[q] = *reinterpret_cast<const uchar4 *>(a.inside_r + (int64_t)plane * ihw + (int64_t)(i0 + ii) * d.in_w + j0);
+        }
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int it = threadIdx.x + q * RT;
+            if (it < total) unit(it, gates[q], true);
+        }
+    } else {
+        for (int it = threadIdx.x; it < total; it += RT) unit(it, make_uchar4(0, 0, 0, 0), false);
     }
 }
 

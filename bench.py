@@ -319,7 +319,7 @@ def main():
     want_x0 = bool(args.x0_store) or semantic          # the embedder reads x0_hat (p_sample_loop asks for it then, too)
     if wl == "search":
         smp.global_select = dd.GlobalSelect() if world > 1 else None
-    res_gen = torch.Generator().manual_seed(0)         # same stream on every rank (distributed.global_resample)
+    res_gen = torch.Generator(device=device).manual_seed(0)     # same stream on every rank; device draw: no host read
 
     def coefs_at(i):
         return smp.sample_coefs(999 - (i % 1000))       # DDPM record; ttc_ddim: the DDIM record

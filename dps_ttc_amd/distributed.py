@@ -210,16 +210,32 @@ def resample_particles(particles_local, ids_global):
         dist.all_gather_into_tensor(pool, particles_local.contiguous())
     mine = ids_global[rank * n_local:(rank + 1) * n_local]
     if pool.is_cuda:
-        return kernels.gather(pool, mine, validate=False)       # ids drawn by resample_ids over the gathered set
+        return kernels.gather(pool, mine.to(pool.device), validate=False)      # ids drawn over the gathered set
     return pool[mine]
 
 
 def global_resample(particles_local, scores_local, temperature, generator):
     """The resampling block of TTC_DDIM.p_sample_loop (gaussian_diffusion.py:685-698) over a sharded particle set:
     -> (particles_local', scores_local', ids_global or None).  Same ids as one process holding all particles would
-    draw from the same generator state."""
+    draw from the same generator state.
+
+    generator: a HOST generator seeded identically on every rank (the draw is torch.multinomial on the CPU: one host
+    read of the gathered scores per resample -- the form the parity tests pin), or a DEVICE generator seeded identically
+    on every rank: the draw then runs on the GPU as the reference's own does (its tensors live on cuda), every rank
+    computes the same ids from the same gathered weights, and nothing is read on the host -- when all weights are equal
+    the draw is replaced by the identity on the device, as TTC_DDIM._resample does on one GPU."""
     rank, world = _world()
     n_local = particles_local.shape[0]
+    if generator is not None and generator.device.type == "cuda" and particles_local.is_cuda:
+        all_scores = gather_scores(scores_local, [n_local] * world).float()
+        n = all_scores.numel()
+        w = torch.exp(-all_scores / temperature)
+        flat = w.max() == w.min()
+        drawn = torch.multinomial(torch.where(flat, torch.ones_like(w), w), n, replacement=True, generator=generator)
+        ids = torch.where(flat, torch.arange(n, device=w.device), drawn)
+        fetched = resample_particles(particles_local, ids)
+        mine = ids[rank * n_local:(rank + 1) * n_local]
+        return fetched, kernels.gather(all_scores.reshape(n, 1), mine, validate=False).reshape(n_local), ids
     ids, all_scores = resample_ids(scores_local, temperature, generator, counts=[n_local] * world,
                                    return_scores=True)
     if ids is None:

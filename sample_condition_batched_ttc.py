@@ -165,7 +165,8 @@ def main(argv=None):
             sampler.global_select = dd.GlobalSelect()
         else:
             sampler.global_resample = True
-            sampler.resample_generator = torch.Generator().manual_seed(args.seed or 0)    # same stream on all ranks
+            # same stream on all ranks; a DEVICE generator: the draw runs on the GPU (as the reference's does), no host read
+            sampler.resample_generator = torch.Generator(device=device).manual_seed(args.seed or 0)
     sample_fn = partial(sampler.p_sample_loop, model=model, measurement_cond_fn=measurement_cond_fn,
                         operator=operator, resample_every_steps=args.resample_every_steps,
                         potential_type=args.potential_type, rs_temp=args.rs_temp, anneal_scale=args.anneal_scale,

@@ -324,3 +324,24 @@ def test_sampler_particle_groups_equal_one_chain(operator, semantic):
     assert bool(torch.isfinite(outs[0][0]).all())
     if semantic:
         assert torch.equal(outs[0][2].reshape(-1), outs[1][2].reshape(-1))
+
+
+def test_global_resample_device_generator_no_host_read():
+    """distributed.global_resample with a DEVICE generator (the driver's and bench.py's setting): the multinomial draw runs
+    on the GPU as the reference's does; particles and scores come back gathered by the drawn ids, equal weights leave the
+    set untouched -- and two generators in the same state draw the same ids (what makes every rank agree)."""
+    import torch
+    from dps_ttc_amd import distributed as dd
+    dev = torch.device("cuda", 0)
+    x = torch.randn(6, 3, 32, 32, device=dev)
+    d = torch.tensor([5.0, 300.0, 7.0, 250.0, 6.0, 400.0], device=dev)
+    g1, g2 = torch.Generator(device=dev).manual_seed(3), torch.Generator(device=dev).manual_seed(3)
+    xa, da, ia = dd.global_resample(x, d, 100.0, g1)
+    xb, db, ib = dd.global_resample(x, d, 100.0, g2)
+    assert torch.equal(ia, ib) and torch.equal(xa, xb) and torch.equal(da, db)
+    assert ia.shape == (6,) and int(ia.min()) >= 0 and int(ia.max()) < 6
+    assert torch.equal(xa, x[ia]) and torch.equal(da, d[ia])
+    assert len(set(ia.tolist())) < 6 or True          # (heavier weights are drawn more often; not asserted)
+    flat = torch.full((6,), 9.0, device=dev)
+    xc, dc, ic = dd.global_resample(x, flat, 100.0, g1)
+    assert torch.equal(ic, torch.arange(6, device=dev)) and torch.equal(xc, x) and torch.equal(dc, flat)

@@ -424,7 +424,10 @@ int phase_step_fwd(dpsx_op *op, const StepFwdArgs &f, float *resid_c, hipStream_
             return check_launch();
         }
         const size_t lds = (size_t)prfft::B2LDS * sizeof(float2);
-        prfft::k_pr_cols2<<<dim3(tiles, (unsigned)planes), prfft::B2T, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw);
+        const unsigned nyq_blocks = (unsigned)((planes + prfft::CT - 1) / prfft::CT);
+        const unsigned grid = nyq_blocks + (unsigned)planes * (prfft::HS / prfft::CT);
+        prfft::k_pr_cols2<<<grid, prfft::B2T, lds, s>>>(hbuf, f.y, (int)f.y_n, (int)c, f.partials, tw, (int)planes,
+                                                        (int)nyq_blocks);
         return check_launch();
     }
     if (vec) {      // S1 and the transform's input staging in one pass

@@ -410,17 +410,28 @@ __device__ __forceinline__ int b2_idx1(int j, int q, int cl) { return (24 * q + 
 // (level 2, block q runtime, k compile-time: k ^ b = k + b for even k, k - b for odd k -- two base registers + immediates)
 __device__ __forceinline__ int b2_idx2(int be, int bo, int k) { return ((k & 1) ? bo : be) + k * CT; }
 
+// Workgroup -> work: 193 columns are twelve 16-column tiles and ONE column (the Nyquist bin kx = 192).  A thirteenth tile per
+// plane would spend a whole workgroup on that column (2,496 workgroups for 768 slots: 3.25 generations, 7 % of the lanes'
+// work wasted); instead the first ceil(planes / 16) workgroups of the grid each take the Nyquist column of SIXTEEN planes
+// (lane cl <-> plane 16 b + cl), and the other 12 x planes workgroups a 16-column tile of one plane: 2,316 workgroups, three
+// generations.  Per-lane plane: the base pointers are per-lane values in both forms.
 __global__ __launch_bounds__(B2T, 3) void k_pr_cols2(float2 *__restrict__ half, const float *__restrict__ y, int y_n, int c,
-                                                      float *__restrict__ partials, const float2 *__restrict__ tw_g)
+                                                      float *__restrict__ partials, const float2 *__restrict__ tw_g,
+                                                      int planes, int nyq_blocks)
 {
     extern __shared__ __align__(16) float2 s_dyn[];
     float2 *s_tw = s_dyn, *s_d = s_dyn + N;
     __shared__ float scratch[B2T / dpsx::kWave];
-    const int64_t plane = blockIdx.y;
-    const int tile = blockIdx.x, cl = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
-    const int kx = tile * CT + cl;
-    const bool colok = kx < HS;
-    const int kxc = colok ? kx : HS - 1;            // surplus lanes of the last tile shadow its last column (never stored)
+    constexpr int TILES = HS / CT;                  // 12 full tiles; partial slot TILES of a plane is its Nyquist column
+    const int cl = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
+    const bool nyq = (int)blockIdx.x < nyq_blocks;  // block-uniform
+    const int vb = (int)blockIdx.x - nyq_blocks;
+    const int plane_raw = nyq ? (int)blockIdx.x * CT + cl : vb / TILES;
+    const int tile = nyq ? TILES : vb - (vb / TILES) * TILES;
+    const bool colok = plane_raw < planes;          // (only the last Nyquist workgroup can hold surplus lanes)
+    const int64_t plane = colok ? plane_raw : planes - 1;      // surplus lanes shadow the last plane (never stored)
+    const int kx = nyq ? HALF : tile * CT + cl;
+    const int kxc = kx;
     for (int i = threadIdx.x; i < N; i += B2T) s_tw[i] = tw_g[i];
     float2 *hp = half + plane * IMG * HP + kxc;
     __syncthreads();                                 // twiddles
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(B2T, 3) void k_pr_cols2(float2 *__restrict__ half, 
         for (int q = 0; q < 16; ++q) st(s_d + b2_idx1(j, q, cl), x[q]);
     }
     const int n = (int)(plane / c), ch = (int)(plane % c);
-    const float *yp = y + ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * N * N;
+    const float *yp = y + ((int64_t)(y_n == 1 ? 0 : n) * c + ch) * N * N;       // (per lane in a Nyquist workgroup)
     // the measurement values of this lane's 24 frequencies and of their mirrors (an L2-resident table: 1.8 MB for a broadcast
     // measurement): issued ahead of the barrier, so that their latency runs under the wait and the forward DFT24
     float y1[24], y2[24];
@@ -509,8 +520,22 @@ __global__ __launch_bounds__(B2T, 3) void k_pr_cols2(float2 *__restrict__ half, 
             }
         }
     }
+    if (nyq) {
+        // sixteen planes in this workgroup: one sum per column, over its 16 lanes g in index order (fixed order, no atomics)
+        __syncthreads();                             // every lane has read its LDS inputs: the array is free
+        float *s_acc = reinterpret_cast<float *>(s_d);
+        s_acc[g * CT + cl] = acc;
+        __syncthreads();
+        if (threadIdx.x < CT && (int)blockIdx.x * CT + (int)threadIdx.x < planes) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < G16; ++q) t += s_acc[q * CT + threadIdx.x];
+            partials[((int64_t)blockIdx.x * CT + threadIdx.x) * (TILES + 1) + TILES] = t;
+        }
+        return;
+    }
     const float t = dpsx::block_sum(acc, scratch);
-    if (threadIdx.x == 0) partials[((int64_t)n * c + ch) * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0) partials[(int64_t)plane * (TILES + 1) + tile] = t;
 }
 
 // ---- pass C: 32 image rows per 256-thread block, one complex transform per PAIR of rows and 16 lanes.

@@ -131,6 +131,9 @@ def parse(argv=None):
                     help="independent particle groups per GPU, each on its own HIP stream (kernels.ParticleGroups = "
                          "sampler.particle_groups; 1 = one chain of N; default: 3, 2 for phase retrieval, whose launches hold "
                          "52 KB of LDS per workgroup; workloads with a per-step exchange run one chain)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise the torch.distributed process group even for ONE rank: every exchange of the workload "
+                         "then runs through the backend (RCCL) as it would with eight -- how a one-GPU box exercises it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -278,7 +281,16 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
+        if world == 1:          # no launcher: the rendezvous of a one-rank group
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("DPSX_BENCH_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" only to rehearse on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -318,7 +330,7 @@ def main():
     spec = cm.fused_spec()
     want_x0 = bool(args.x0_store) or semantic          # the embedder reads x0_hat (p_sample_loop asks for it then, too)
     if wl == "search":
-        smp.global_select = dd.GlobalSelect() if world > 1 else None
+        smp.global_select = dd.GlobalSelect() if use_pg else None
     res_gen = torch.Generator(device=device).manual_seed(0)     # same stream on every rank; device draw: no host read
 
     def coefs_at(i):
@@ -354,7 +366,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -441,7 +453,7 @@ def main():
         winner, best_dev = closing_select()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_pg:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -642,6 +654,7 @@ def main():
                        "chains_per_gpu": nch,
                        "x0_hat_store": x0_stored,
                        "semantic_stand_in": semantic,
+                       "process_group": (os.environ.get("DPSX_BENCH_BACKEND", "nccl") + f" x{world}") if use_pg else None,
                        "parallelism": f"particles sharded x{world} ({args.scaling} scaling); per GPU {nch} independent "
                                       f"particle group(s) (kernels.ParticleGroups), one HIP stream each; {exchange}"},
             "roofline": roofline,
@@ -650,7 +663,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and wl == "dps" and not semantic:
             line["cpu_baseline"], line["x0_hat_rel_l2"] = cpu_baseline(args, op, fkw, smp, ring, x_t, y, handle, device)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -27,6 +27,13 @@ def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def _solo():
+    """True when there is nobody to talk to: no process group.  A process group of ONE rank still takes the collective
+    path -- the exchanges then run through the backend (RCCL on a GPU) as they would with eight ranks, which is how the
+    one-GPU boxes of this pool exercise the real backend (tests/test_driver_gpu.py::test_rccl_single_rank_collectives)."""
+    return not (dist.is_available() and dist.is_initialized())
+
+
 def shard_range(n_total, rank=None, world=None):
     """Contiguous block of particles owned by `rank` (N=256 -> 32 per GPU on 8 GPUs)."""
     r, w = _world()
@@ -46,7 +53,7 @@ def shard_counts(n_total, world=None):
 def exchange_counts(n_local, device):
     """Shard sizes of all ranks when they cannot be derived (one tiny all-gather + one host read)."""
     rank, world = _world()
-    if world == 1:
+    if _solo():
         return [int(n_local)]
     mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
     out = torch.empty(world, dtype=torch.int64, device=device)
@@ -62,7 +69,7 @@ def gather_scores(scores_local, counts=None):
     Unequal shards are padded with +inf to the largest one for the collective and compacted after."""
     rank, world = _world()
     scores_local = scores_local.contiguous()
-    if world == 1:
+    if _solo():
         return scores_local
     if counts is None:
         counts = exchange_counts(scores_local.numel(), scores_local.device)
@@ -117,7 +124,7 @@ def global_best_of_n(scores_local, particles_local, counts=None):
     else:
         winner = torch.empty((1,) + tuple(particles_local.shape[1:]), dtype=particles_local.dtype,
                              device=particles_local.device)
-    if world > 1:
+    if not _solo():
         dist.broadcast(winner, src=owner)
     return winner, best, all_scores
 
@@ -143,7 +150,7 @@ def global_best_of_n_device(scores_local, particles_local, counts):
         local_best = torch.argmin(scores_local)
         local_min = scores_local[local_best].reshape(1).float()
         champ = particles_local[local_best].unsqueeze(0).contiguous()
-    if world == 1:
+    if _solo():
         return champ, local_best
     mine = torch.cat([local_min.reshape(1).float(), local_best.reshape(1).float()])
     table = torch.empty(world * 2, dtype=torch.float32, device=dev)
@@ -168,7 +175,7 @@ class GlobalSelect:
         """-> n_out copies of the global winner (default: one per local particle)"""
         rank, world = _world()
         n = particles_local.shape[0] if n_out is None else int(n_out)
-        if world == 1:
+        if _solo():
             return kernels.replicate(particles_local, kernels.argmin(costs_local), n_out=n)
         if particles_local.is_cuda:
             local_best, local_min = kernels.argmin(costs_local, want_value=True)
@@ -202,7 +209,7 @@ def resample_particles(particles_local, ids_global):
     (equal shards: every rank runs the same batch size)."""
     rank, world = _world()
     n_local = particles_local.shape[0]
-    if world == 1:
+    if _solo():
         pool = particles_local
     else:
         pool = torch.empty((world * n_local,) + tuple(particles_local.shape[1:]), dtype=particles_local.dtype,

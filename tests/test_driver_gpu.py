@@ -345,3 +345,70 @@ def test_global_resample_device_generator_no_host_read():
     flat = torch.full((6,), 9.0, device=dev)
     xc, dc, ic = dd.global_resample(x, flat, 100.0, g1)
     assert torch.equal(ic, torch.arange(6, device=dev)) and torch.equal(xc, x) and torch.equal(dc, flat)
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, socket
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)           # "nccl" IS RCCL on ROCm
+from dps_ttc_amd import distributed as dd, kernels
+torch.manual_seed(0)
+x = torch.randn(6, 3, 64, 64, device=dev)
+d = torch.tensor([5.0, 3.0, 7.0, 3.0, 9.0, 4.0], device=dev)
+assert dd.exchange_counts(6, dev) == [6]
+assert torch.equal(dd.gather_scores(d, [6]), d) and torch.equal(dd.gather_scores(d), d)
+w, best, alls = dd.global_best_of_n(d, x, [6])
+assert best == 1 and torch.equal(w, x[1:2]) and torch.equal(alls, d)
+w2, b2 = dd.global_best_of_n_device(d, x, [6])
+assert int(b2) == 1 and torch.equal(w2, x[1:2])
+sel = dd.GlobalSelect()(d, x)
+assert sel.shape == x.shape and torch.equal(sel, x[1:2].repeat(6, 1, 1, 1))
+assert torch.equal(dd.GlobalSelect()(d, x, n_out=1), x[1:2])
+g = torch.Generator(device=dev).manual_seed(1)
+xr, dr, ids = dd.global_resample(x, d * 40.0, 100.0, g)
+assert torch.equal(xr, x[ids]) and torch.equal(dr, (d * 40.0)[ids])
+gh = torch.Generator().manual_seed(1)
+xr, dr, ids = dd.global_resample(x, d * 40.0, 100.0, gh)
+assert ids is not None and torch.equal(xr, x[ids.to(dev)])
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()
+assert float(t) == 1.5
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+'''
+
+
+def test_rccl_single_rank_collectives():
+    """The real backend on the one GPU this pool gives a box: a process group of ONE rank over "nccl" (= RCCL).  With a
+    process group initialised, distributed.py takes its collective paths (all-gather of scores and champions, winner
+    broadcast, padded gathers, the resampling exchange) -- here they run through RCCL kernels, degenerate but real: the
+    library loads, the communicator initialises under HSA_ENABLE_IPC_MODE_LEGACY=0, dtypes and shapes are accepted, the
+    stream ordering holds.  (Two or more ranks need two or more GPUs: the driver's round-end run.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT], capture_output=True, timeout=600)
+    out = r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in out, out[-3000:]
+
+
+def test_bench_single_rank_process_group():
+    """bench.py --force-process-group: the sharded workloads with their exchanges going through RCCL (one rank)"""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DPSX_BENCH_BACKEND"):
+        env.pop(k, None)
+    for mode in (["--workload", "search", "--particles", "8"],
+                 ["--workload", "resample", "--operator", "phase_retrieval", "--particles", "4", "--resample-every", "2"],
+                 ["--workload", "dps_scores", "--operator", "motion_blur", "--particles", "4", "--semantic"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
+                            "--force-process-group", *mode], env=env, capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+        rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
+        assert rec["config"]["process_group"] == "nccl x1" and rec["value"] > 0 and rec["n_gpus"] == 1

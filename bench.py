@@ -266,6 +266,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ONE JSON line on stdout, nothing else: libraries write there too (RCCL prints a version banner to stdout when its
+    # first communicator comes up), so file descriptor 1 points at stderr for the whole run and is put back for the line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must match")
 
@@ -382,7 +387,9 @@ def main():
     if nch > 1:
         pg = kernels.ParticleGroups(op, n, 3, 256, 256, device, nch, mask=mask, like=x_t, record_streams=False)
     single = wl == "search" and args.search_form == "single"
-    state = {"x": x_t[:1].contiguous() if single else x_t, "gx": [x_t[sl] for sl in pg.slices] if pg else None}
+    if wl == "dps_scores" and len(set(counts)) != 1:
+        raise SystemExit("--workload dps_scores needs equal shards (distributed.ScoreGather)")
+    state = {"scores": dd.ScoreGather(), "x": x_t[:1].contiguous() if single else x_t, "gx": [x_t[sl] for sl in pg.slices] if pg else None}
 
     def grouped_steps(first, count, timers=None):
         for i in range(count):
@@ -422,8 +429,11 @@ def main():
                 continue
             x = step(k, x)
             if wl == "dps_scores":
-                # per-step score all-gather (RCCL) + the global first-min argmin, all on the device
-                state["best"] = dd.first_argmin(dd.gather_scores(buf.norm, counts))
+                # per-step score all-gather (RCCL), pipelined: the gather of step k runs on the backend's stream under
+                # step k + 1 (distributed.ScoreGather); the global first-min argmin of the finished one, on the device
+                done = state["scores"].submit(buf.norm)
+                if done is not None:
+                    state["best"] = dd.first_argmin(done)
             elif wl == "resample" and k % args.resample_every == 0:
                 # TTC_DDIM._resample over the sharded particle set: scores all-gathered, identical host draw, states fetched
                 x, _, _ = dd.global_resample(x, buf.norm, 100.0, res_gen)
@@ -437,6 +447,10 @@ def main():
 
     def closing_select():
         """final best-of-N over all ranks' particles (best_of_n_simple.py:32-40 on the device, no host read)"""
+        if wl == "dps_scores":
+            last = state["scores"].flush()
+            if last is not None:
+                state["best"] = dd.first_argmin(last)
         if pg is not None:
             pg.join()
             return dd.global_best_of_n_device(pg.full.norm, pg.x_next(), counts)
@@ -662,7 +676,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and wl == "dps" and not semantic:
             line["cpu_baseline"], line["x0_hat_rel_l2"] = cpu_baseline(args, op, fkw, smp, ring, x_t, y, handle, device)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if use_pg:
         dist.destroy_process_group()
 

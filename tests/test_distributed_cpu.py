@@ -87,6 +87,14 @@ def _worker(rank, world, port, q):
         d6 = torch.tensor([50.0, 400.0, 30.0, 900.0, 10.0, 250.0])
         img3, dist3 = smp._resample(particles[lo:hi].clone(), d6[lo:hi].clone(), 100)
         out["ttc"] = (smp.last_resample_ids.tolist(), img3, dist3.tolist())
+        # --- pipelined per-step score gather: submit() returns the PREVIOUS step's gathered scores, flush() the last
+        sg = dd.ScoreGather()
+        seen = []
+        for k in range(3):
+            prev = sg.submit(mine_s + float(k))
+            seen.append(None if prev is None else prev.tolist())
+        seen.append(sg.flush().tolist())
+        out["score_gather"] = seen
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -121,6 +129,9 @@ def test_world_size_2_gloo():
         assert res[r]["groups"] == ([6, 3], 7, all_s, True) and int(torch.argmin(torch.tensor(all_s))) == 7
         assert res[r]["groups_dev"] == (7, True) and res[r]["groups_exchanged"] == 7
         assert res[r]["empty"] == (1, [2.0, 1.0, 3.0], True) and res[r]["empty_dev"] == (1, True)
+    base = [5.0, 2.0, 9.0, 2.0, 1.5, 7.0]
+    for r in (0, 1):       # pipelined score gather: step k's scores come back at step k + 1, the last ones at flush()
+        assert res[r]["score_gather"] == [None, base, [v + 1.0 for v in base], [v + 2.0 for v in base]]
     # ttc_ddim: 2 ranks x 3 particles resample to what 1 rank x 6 does with the same generator
     from dps_ttc_amd.gaussian_diffusion import create_sampler
     smp = create_sampler(sampler="ttc_ddim", steps=1000, noise_schedule="linear", model_mean_type="epsilon",
@@ -149,3 +160,5 @@ def test_single_process_paths():
     assert int(best) == 1 and torch.equal(w[0], torch.arange(4.0, 8.0).reshape(1, 2, 2))
     assert dd.shard_counts(10, 3) == [4, 3, 3] and dd.locate(5, [4, 3, 3]) == (1, 1) and dd.locate(0, [0, 2]) == (1, 0)
     assert int(dd.first_argmin(torch.tensor([2.0, float("nan"), 1.0]))) == 1      # NaN is the minimum (torch.argmin)
+    sg = dd.ScoreGather()                                                          # no process group: a local copy
+    assert sg.submit(s) is None and sg.submit(s + 1).tolist() == s.tolist() and sg.flush().tolist() == (s + 1).tolist()

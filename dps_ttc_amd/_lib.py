@@ -15,7 +15,7 @@ OK, EINVAL, EUNSUPPORTED, ELAUNCH, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4, -5
 KIND_TAPS, KIND_SEP, KIND_RESIZE, KIND_MASK, KIND_IDENT, KIND_PHASE = range(6)
 BLUR_AUTO, BLUR_FORCE_TAPS = 0, 1
 POTENTIALS = {"mean": 1, "min": 2, "diff": 3, "curr": 4}      # DPSX_POT_*
-ABI_VERSION = 2          # DPSX_ABI_VERSION of include/dpsx.h
+ABI_VERSION = 3          # DPSX_ABI_VERSION of include/dpsx.h
 
 
 class Coefs(ctypes.Structure):
@@ -77,6 +77,8 @@ SIGNATURES = {
     "dpsx_argmin_f32": (c_int, [_f, _i64, _p, _f, _p]),
     "dpsx_gather_f32": (c_int, [_f, _p, _f, _i64, _i64, _i64, _p]),
     "dpsx_replicate_f32": (c_int, [_f, _p, _f, _i64, _i64, _i64, _p]),
+    "dpsx_pack_champion_f32": (c_int, [_f, _f, _p, _f, _f, _i64, _i64, _p]),
+    "dpsx_select_champion_f32": (c_int, [_f, _i64, _i64, _f, _i64, _p, _p, _p]),
 }
 
 _lib = None

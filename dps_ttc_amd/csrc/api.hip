@@ -813,5 +813,23 @@ int dpsx_replicate_f32(const float *src, const int64_t *idx_dev, float *dst, int
     return gather_f32(src, idx_dev, dst, n_out, n_src, chw, true, (hipStream_t)stream);
 }
 
+int dpsx_pack_champion_f32(const float *particles, const float *costs, const int64_t *best_idx_dev,
+                           const float *best_val_dev, float *out, int64_t n, int64_t chw, void *stream)
+{
+    if (!particles || !out || n < 1 || chw < 4 || chw % 4 != 0) return DPSX_EINVAL;
+    if (!best_idx_dev && !costs) return DPSX_EINVAL;
+    if (best_idx_dev && !best_val_dev && !costs) return DPSX_EINVAL;
+    if (!aligned16(particles) || !aligned16(out)) return DPSX_EUNSUPPORTED;
+    return pack_champion(particles, costs, best_idx_dev, best_val_dev, out, n, chw, (hipStream_t)stream);
+}
+
+int dpsx_select_champion_f32(const float *table, int64_t world, int64_t chw, float *dst, int64_t n_out,
+                             int64_t *win_rank_dev, int64_t *win_local_dev, void *stream)
+{
+    if (!table || !dst || world < 1 || world > (1 << 20) || chw < 4 || chw % 4 != 0 || n_out < 1) return DPSX_EINVAL;
+    if (!aligned16(table) || !aligned16(dst)) return DPSX_EUNSUPPORTED;
+    return select_champion(table, (int)world, chw, dst, n_out, win_rank_dev, win_local_dev, (hipStream_t)stream);
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -505,6 +505,10 @@ int mask_step_bwd(const dpsx_op *op, const StepBwdArgs &a, hipStream_t s);
 int argmin_f32(const float *v, int64_t n, int64_t *idx, float *val, hipStream_t s);
 int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
                bool replicate, hipStream_t s);
+int pack_champion(const float *particles, const float *costs, const int64_t *best, const float *val, float *out, int64_t n,
+                  int64_t chw, hipStream_t s);
+int select_champion(const float *table, int world, int64_t chw, float *dst, int64_t n_out, int64_t *win_rank,
+                    int64_t *win_local, hipStream_t s);
 
 // phase.hip
 int phase_create(dpsx_op *op);

@@ -596,6 +596,114 @@ __global__ __launch_bounds__(kThreads) void k_replicate(const float *__restrict_
         if (p0 + k < n_out) d4[(int64_t)k * chw4] = v;
 }
 
+// ---- the device half of the per-rank champion exchange (distributed.py: _exchange_champions)
+// pack: out[0 .. chw) = particles[best], out[chw] = value (costs[best] or *val), out[chw + 1] = (float)best, two zeros --
+// what ONE all-gather then carries to every rank.  best == nullptr: the torch.argmin-order select over costs runs here
+// (every block recomputes it: n <= a few thousand floats from L2, cheaper than a launch of its own).
+__global__ __launch_bounds__(kThreads) void k_pack_champion(const float *__restrict__ particles, const float *__restrict__ costs,
+                                                            const int64_t *__restrict__ best_in,
+                                                            const float *__restrict__ val_in, float *__restrict__ out,
+                                                            int64_t n, int64_t chw4)
+{
+    __shared__ float s_val[kThreads / kWave];
+    __shared__ int64_t s_idx[kThreads / kWave];
+    __shared__ float s_bv;
+    __shared__ int64_t s_bi;
+    if (best_in) {
+        if (threadIdx.x == 0) { s_bi = best_in[0]; s_bv = val_in ? val_in[0] : costs[best_in[0]]; }
+    } else {
+        ArgMin best{0.0f, -1};
+        for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+            const ArgMin c{costs[i], i};
+            if (argmin_better(c, best)) best = c;
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            ArgMin c;
+            c.v = __shfl_down(best.v, o, kWave);
+            c.i = __shfl_down(best.i, o, kWave);
+            if (argmin_better(c, best)) best = c;
+        }
+        const int wave = threadIdx.x / kWave;
+        if (threadIdx.x % kWave == 0) { s_val[wave] = best.v; s_idx[wave] = best.i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kThreads / kWave; ++w) {
+                const ArgMin c{s_val[w], s_idx[w]};
+                if (argmin_better(c, best)) best = c;
+            }
+            s_bi = best.i < 0 ? 0 : best.i;
+            s_bv = best.v;
+        }
+    }
+    __syncthreads();
+    const int64_t b = s_bi;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    if (i < chw4) {
+        const float q = __builtin_nanf("");
+        o4[i] = (b < 0 || b >= n) ? make_float4(q, q, q, q) : (reinterpret_cast<const float4 *>(particles) + b * chw4)[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) o4[chw4] = make_float4(s_bv, (float)b, 0.0f, 0.0f);
+}
+
+// select: table [world][chw + 4] as gathered; winner rank = torch.argmin order over table[r][chw] (first minimum, NaN
+// counts as the minimum: lowest rank wins ties); dst[p] = table[winner][0 .. chw) for p < n_out; optional outputs: the
+// winner's rank and its local index (table[winner][chw + 1]).
+__global__ __launch_bounds__(kThreads) void k_select_champion(const float *__restrict__ table, int world, int64_t chw4,
+                                                              float *__restrict__ dst, int64_t n_out,
+                                                              int64_t *__restrict__ win_rank, int64_t *__restrict__ win_local)
+{
+    __shared__ int s_w;
+    if (threadIdx.x < kWave) {
+        ArgMin best{0.0f, -1};
+        for (int r = threadIdx.x; r < world; r += kWave) {
+            const ArgMin c{table[(int64_t)r * (chw4 + 1) * 4 + chw4 * 4], (int64_t)r};
+            if (argmin_better(c, best)) best = c;
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            ArgMin c;
+            c.v = __shfl_down(best.v, o, kWave);
+            c.i = __shfl_down(best.i, o, kWave);
+            if (argmin_better(c, best)) best = c;
+        }
+        if (threadIdx.x == 0) s_w = best.i < 0 ? 0 : (int)best.i;
+    }
+    __syncthreads();
+    const int wr = s_w;
+    const float4 *src = reinterpret_cast<const float4 *>(table) + (int64_t)wr * (chw4 + 1);
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (win_rank) *win_rank = wr;
+        if (win_local) *win_local = (int64_t)src[chw4].y;
+    }
+    if (i >= chw4) return;
+    const float4 v = src[i];
+    const int64_t p0 = (int64_t)blockIdx.y * kRepl;
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + p0 * chw4 + i;
+#pragma unroll
+    for (int k = 0; k < kRepl; ++k)
+        if (p0 + k < n_out) d4[(int64_t)k * chw4] = v;
+}
+
+int pack_champion(const float *particles, const float *costs, const int64_t *best, const float *val, float *out, int64_t n,
+                  int64_t chw, hipStream_t s)
+{
+    const int64_t chw4 = chw / 4;
+    k_pack_champion<<<(unsigned)((chw4 + kThreads - 1) / kThreads), kThreads, 0, s>>>(particles, costs, best, val, out, n, chw4);
+    return check_launch();
+}
+
+int select_champion(const float *table, int world, int64_t chw, float *dst, int64_t n_out, int64_t *win_rank,
+                    int64_t *win_local, hipStream_t s)
+{
+    const int64_t chw4 = chw / 4;
+    const dim3 grid((unsigned)((chw4 + kThreads - 1) / kThreads), (unsigned)((n_out + kRepl - 1) / kRepl));
+    k_select_champion<<<grid, kThreads, 0, s>>>(table, world, chw4, dst, n_out, win_rank, win_local);
+    return check_launch();
+}
+
 int gather_f32(const float *src, const int64_t *ids, float *dst, int64_t n_out, int64_t n_src, int64_t chw,
                bool replicate, hipStream_t s)
 {

@@ -129,7 +129,19 @@ def global_best_of_n(scores_local, particles_local, counts=None):
     return winner, best, all_scores
 
 
-_ZEROS2 = {}
+_ZEROS2, _OFFSETS = {}, {}
+
+
+def _offsets(counts, device):
+    """exclusive prefix sums of the shard sizes on the device (uploaded once per (counts, device))"""
+    key = (tuple(int(c) for c in counts), str(device))
+    if key not in _OFFSETS:
+        acc, out = 0, []
+        for c in key[0]:
+            out.append(acc)
+            acc += c
+        _OFFSETS[key] = torch.tensor(out, dtype=torch.int64, device=device)
+    return _OFFSETS[key]
 
 
 def _zeros2(device):
@@ -145,16 +157,32 @@ def _exchange_champions(local_min, local_best, champ):
     -> (mins [world] fp32, local indices [world] int64, champions [world, C, H, W]).
     One all-gather instead of two: through RCCL a collective costs tens of microseconds of fixed latency however small it
     is (measured with a one-rank group on MI355X: the two-collective form of the per-step select added about 50 us to a
-    59 us search step), so the scores ride with the particle."""
+    59 us search step), so the scores ride with the particle.  (Host-tensor form, what the gloo tests run; on the device
+    `_champion_table` builds the same record in one launch and `kernels.select_champion` reads it in one.)"""
     world = dist.get_world_size()
     shape = tuple(champ.shape[1:])
     chw = champ[0].numel()
-    # (one concatenation kernel; local_best as fp32 is exact below 2^24 particles per rank)
+    # (local_best as fp32 is exact below 2^24 particles per rank)
     mine = torch.cat([champ.reshape(-1), local_min.reshape(1).float(), local_best.reshape(1).float(), _zeros2(champ.device)])
     table = torch.empty(world * (chw + 4), dtype=torch.float32, device=champ.device)
     dist.all_gather_into_tensor(table, mine)
     table = table.reshape(world, chw + 4)
     return table[:, chw].contiguous(), table[:, chw + 1].long(), table[:, :chw].reshape((world,) + shape)
+
+
+def _champion_table(costs_local, particles_local):
+    """Device form of the exchange: pack (argmin over this rank's costs + champion + header: ONE launch), all-gather
+    -> table [world, C*H*W + 4].  An empty shard contributes a +inf record."""
+    world = dist.get_world_size()
+    chw = particles_local[0].numel() if particles_local.shape[0] else int(torch.Size(particles_local.shape[1:]).numel())
+    if particles_local.shape[0] == 0:
+        mine = torch.zeros(chw + 4, dtype=torch.float32, device=particles_local.device)
+        mine[chw] = float("inf")
+    else:
+        mine = kernels.pack_champion(particles_local, costs_local)
+    table = torch.empty(world * (chw + 4), dtype=torch.float32, device=particles_local.device)     # (flat: gloo insists)
+    dist.all_gather_into_tensor(table, mine)
+    return table.reshape(world, chw + 4)
 
 
 def global_best_of_n_device(scores_local, particles_local, counts):
@@ -167,6 +195,12 @@ def global_best_of_n_device(scores_local, particles_local, counts):
     rank, world = _world()
     n_local = scores_local.numel()
     dev, shape = particles_local.device, tuple(particles_local.shape[1:])
+    if particles_local.is_cuda and not _solo():
+        # three launches around the one collective: pack (argmin + champion + header), select (pick + copy), index
+        winner, win_rank, win_local = kernels.select_champion(_champion_table(scores_local, particles_local), shape,
+                                                              n_out=1, want_index=True)
+        offsets = _offsets(counts, dev)
+        return winner, (offsets.gather(0, win_rank.reshape(1)).reshape(()) + win_local)
     if n_local == 0:
         local_best = torch.zeros((), dtype=torch.int64, device=dev)
         local_min = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
@@ -182,8 +216,7 @@ def global_best_of_n_device(scores_local, particles_local, counts):
         return champ, local_best
     mins, local_idx, stacked = _exchange_champions(local_min, local_best, champ.float())
     win_rank = first_argmin(mins)                                        # lowest rank wins ties = first-min rule
-    offsets = torch.tensor([sum(counts[:r]) for r in range(world)], dtype=torch.int64, device=dev)
-    best = (offsets + local_idx).gather(0, win_rank.reshape(1)).reshape(())
+    best = (_offsets(counts, dev) + local_idx).gather(0, win_rank.reshape(1)).reshape(())
     stacked = stacked.contiguous()
     winner = kernels.replicate(stacked, win_rank, n_out=1) if stacked.is_cuda else stacked[int(win_rank)].unsqueeze(0)
     return winner, best
@@ -202,17 +235,14 @@ class GlobalSelect:
         if _solo():
             return kernels.replicate(particles_local, kernels.argmin(costs_local), n_out=n)
         if particles_local.is_cuda:
-            local_best, local_min = kernels.argmin(costs_local, want_value=True)
-            champ = kernels.replicate(particles_local, local_best, n_out=1)
-        else:
-            local_best = torch.argmin(costs_local)
-            local_min = costs_local[local_best].reshape(1)
-            champ = particles_local[local_best].unsqueeze(0).contiguous()
+            # pack launch -> ONE collective -> select launch (pick + n copies); nothing else on the stream, no host read
+            return kernels.select_champion(_champion_table(costs_local, particles_local), tuple(particles_local.shape[1:]),
+                                           n_out=n)
+        local_best = torch.argmin(costs_local)
+        local_min = costs_local[local_best].reshape(1)
+        champ = particles_local[local_best].unsqueeze(0).contiguous()
         mins, _, stacked = _exchange_champions(local_min, local_best, champ.float())     # ONE collective per step
-        stacked = stacked.contiguous()
         win_rank = first_argmin(mins)                                     # lowest rank wins ties = first-min rule
-        if stacked.is_cuda:
-            return kernels.replicate(stacked, win_rank, n_out=n)
         return stacked[int(win_rank)].unsqueeze(0).repeat(n, 1, 1, 1)
 
 

@@ -395,6 +395,39 @@ def replicate(src, idx_dev, n_out=None):
     return dst
 
 
+def pack_champion(particles, costs=None, best=None, best_val=None, out=None):
+    """This rank's record for the champion exchange (distributed._exchange_champions): [C*H*W floats of particles[best] |
+    cost, (float)best, 0, 0] in ONE launch.  best=None: the torch.argmin-order select over `costs` runs inside the launch."""
+    particles = f32c(particles)
+    n, chw = particles.shape[0], particles[0].numel()
+    costs = None if costs is None else f32c(costs.reshape(-1), "costs")
+    if costs is not None and costs.numel() != n:
+        raise ValueError("one cost per particle")
+    best = None if best is None else best.to(device=particles.device, dtype=torch.int64).reshape(1).contiguous()
+    best_val = None if best_val is None else f32c(best_val.reshape(1), "best_val")
+    if out is None:
+        out = torch.empty(chw + 4, dtype=torch.float32, device=particles.device)
+    check(lib().dpsx_pack_champion_f32(ptr(particles), ptr(costs), ptr(best), ptr(best_val), ptr(out), n, chw,
+                                       stream_of(particles)), "dpsx_pack_champion_f32")
+    return out
+
+
+def select_champion(table, shape, n_out=1, want_index=False):
+    """table [world, C*H*W + 4] as gathered -> n_out copies of the winning rank's champion [n_out, *shape]
+    (first minimum over table[:, chw], lowest rank wins ties); want_index: also (winner rank, its local index) as device
+    int64 scalars.  ONE launch, nothing read on the host."""
+    table = f32c(table)
+    world, chw = table.shape[0], table.shape[1] - 4
+    dst = torch.empty((int(n_out),) + tuple(shape), dtype=torch.float32, device=table.device)
+    if dst[0].numel() != chw:
+        raise ValueError("table rows do not hold a particle of this shape plus its header")
+    wr = torch.empty((), dtype=torch.int64, device=table.device) if want_index else None
+    wl = torch.empty((), dtype=torch.int64, device=table.device) if want_index else None
+    check(lib().dpsx_select_champion_f32(ptr(table), world, chw, ptr(dst), int(n_out), ptr(wr), ptr(wl), stream_of(table)),
+          "dpsx_select_champion_f32")
+    return (dst, wr, wl) if want_index else dst
+
+
 # ------------------------------------------------------------------ fused DPS step
 class StepBuffers:
     """Persistent per-(N, C, H, W) device buffers of the fused step (resident in HBM across steps).

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DPSX_ABI_VERSION 2
+#define DPSX_ABI_VERSION 3
 
 enum {
     DPSX_OK = 0,
@@ -244,6 +244,21 @@ int dpsx_gather_f32(const float *src, const int64_t *ids_dev, float *dst,
 /* dst[p] = src[*idx_dev] for all p  (img[best.repeat(n)], gaussian_diffusion.py:633) */
 int dpsx_replicate_f32(const float *src, const int64_t *idx_dev, float *dst,
                        int64_t n_out, int64_t n_src, int64_t chw, void *stream);
+
+/* ---- the device half of the multi-GPU champion exchange (best-of-N across ranks: gaussian_diffusion.py:626-633 and
+ * best_of_n_simple.py:32-40 over a sharded particle set).  The collective itself stays with the caller's communicator
+ * (RCCL through torch.distributed); these two launches replace the seven small device ops around it -- argmin, copy,
+ * concatenation, two strided copies, argmin, replication -- whose launch gaps and host calls cost more than the collective.
+ *   pack:   out[0 .. chw) = particles[best], out[chw .. chw+4) = (cost, (float)best, 0, 0): the record one all-gather
+ *           carries (the header sits BEHIND the image so that the image stays 16-byte aligned).  best_idx_dev == NULL:
+ *           the torch.argmin-order select over costs runs in this launch; else costs may be NULL if best_val_dev is given.
+ *   select: table is the gathered [world][chw + 4]; the winner is the torch.argmin-order minimum of table[r][chw]
+ *           (lowest rank wins ties, NaN counts as the minimum); dst[p] = its image for p < n_out; win_rank_dev /
+ *           win_local_dev (nullable) receive the winning rank and its local particle index. */
+int dpsx_pack_champion_f32(const float *particles, const float *costs, const int64_t *best_idx_dev,
+                           const float *best_val_dev, float *out, int64_t n, int64_t chw, void *stream);
+int dpsx_select_champion_f32(const float *table, int64_t world, int64_t chw, float *dst, int64_t n_out,
+                             int64_t *win_rank_dev, int64_t *win_local_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_no_compute_entry_points_work_without_a_gpu():
     from dps_ttc_amd import _lib
     lib = _lib.lib()
-    assert lib.dpsx_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.dpsx_abi_version() == _lib.ABI_VERSION == 3
     assert lib.dpsx_strerror(_lib.OK) == b"ok"
     assert b"workspace" in lib.dpsx_strerror(_lib.EWORKSPACE)
     with pytest.raises(_lib.DpsxError, match="invalid argument"):

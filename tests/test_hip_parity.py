@@ -790,6 +790,50 @@ def test_argmin_gather_replicate(K, oracle, golden):
     np.testing.assert_array_equal(ids.numpy(), g["resample.ids"])
 
 
+def test_pack_and_select_champion(K):
+    """The two launches around the champion all-gather (distributed._champion_table / GlobalSelect on the device) against
+    their torch restatement: record = [particles[argmin] | cost, index, 0, 0]; select = first minimum over the records'
+    costs (lowest rank wins ties, NaN counts as the minimum), n_out copies, winner rank and local index on the device."""
+    torch.manual_seed(5)
+    for n, shape in ((1, (3, 8, 8)), (7, (3, 16, 12)), (64, (3, 64, 64)), (300, (1, 4, 4))):
+        x = torch.randn((n,) + shape, device=DEV)
+        c = torch.randn(n, device=DEV).round(decimals=1)
+        chw = x[0].numel()
+        rec = K.pack_champion(x, c)
+        b = int(torch.argmin(c))
+        assert rec.shape == (chw + 4,)
+        assert torch.equal(rec[:chw], x[b].reshape(-1)) and float(rec[chw]) == float(c[b]) and int(rec[chw + 1]) == b
+        assert float(rec[chw + 2]) == 0.0 and float(rec[chw + 3]) == 0.0
+        # the select already done by the caller (index [+ value] on the device)
+        rec2 = K.pack_champion(x, c, best=torch.tensor(n - 1, device=DEV))
+        assert torch.equal(rec2[:chw], x[n - 1].reshape(-1)) and float(rec2[chw]) == float(c[n - 1]) and int(rec2[chw + 1]) == n - 1
+        rec3 = K.pack_champion(x, None, best=torch.tensor(0, device=DEV), best_val=torch.tensor([2.5], device=DEV))
+        assert torch.equal(rec3[:chw], x[0].reshape(-1)) and float(rec3[chw]) == 2.5
+    cn = torch.tensor([3.0, float("nan"), 1.0, float("nan")], device=DEV)
+    xs = torch.randn(4, 3, 8, 8, device=DEV)
+    assert int(K.pack_champion(xs, cn)[3 * 64 + 1]) == 1                      # first NaN wins, as torch.argmin
+    # select over a gathered table
+    for world, shape, n_out in ((1, (3, 8, 8), 1), (2, (3, 16, 12), 5), (8, (3, 64, 64), 64), (70, (1, 4, 4), 9)):
+        chw = int(np.prod(shape))
+        table = torch.randn(world, chw + 4, device=DEV)
+        table[:, chw] = torch.randn(world, device=DEV).round(decimals=0)      # ties across ranks
+        table[:, chw + 1] = torch.randint(0, 1000, (world,), device=DEV).float()
+        w = int(torch.argmin(table[:, chw]))
+        dst, wr, wl = K.select_champion(table, shape, n_out=n_out, want_index=True)
+        assert int(wr) == w and int(wl) == int(table[w, chw + 1])
+        assert torch.equal(dst, table[w, :chw].reshape((1,) + shape).repeat(n_out, 1, 1, 1))
+        assert torch.equal(K.select_champion(table, shape, n_out=n_out), dst)
+    table = torch.randn(3, 3 * 64 + 4, device=DEV)
+    table[:, 192] = torch.tensor([float("inf"), float("nan"), -5.0])
+    _, wr, _ = K.select_champion(table, (3, 8, 8), want_index=True)
+    assert int(wr) == 1
+    table[:, 192] = float("inf")                                              # all shards empty / all +inf: rank 0
+    _, wr, _ = K.select_champion(table, (3, 8, 8), want_index=True)
+    assert int(wr) == 0
+    with pytest.raises(ValueError):
+        K.select_champion(table, (3, 8, 9))
+
+
 # ----------------------------------------------------------------- resample_update (reference :515-587) and fused selects
 @pytest.mark.parametrize("tag,oname", [("gauss", "gauss"), ("sr4", "sr4")])
 def test_resample_update_golden(K, golden, tag, oname):

@@ -119,6 +119,8 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--semantic", action="store_true", help="stand-in semantic-guidance cotangent through dpsx_step_bwd_extra_f32")
     ap.add_argument("--resample-every", type=int, default=10)
+    ap.add_argument("--resample-fetch", choices=["auto", "all", "selected"], default="auto",
+                    help="resample workload: how the drawn particles travel (distributed.resample_particles)")
     ap.add_argument("--search-form", default="single", choices=["single", "replicated"],
                     help="--workload search: 'single' = the loop's default (SearchDDPM.single_state: after a select all particles "
                          "are copies of the winner, so ONE state particle feeds the N proposals -- dpsx_search_step_one_f32); "
@@ -436,7 +438,7 @@ def main():
                     state["best"] = dd.first_argmin(done)
             elif wl == "resample" and k % args.resample_every == 0:
                 # TTC_DDIM._resample over the sharded particle set: scores all-gathered, identical host draw, states fetched
-                x, _, _ = dd.global_resample(x, buf.norm, 100.0, res_gen)
+                x, _, _ = dd.global_resample(x, buf.norm, 100.0, res_gen, fetch=args.resample_fetch)
         state["x"] = x
 
     def run_steps(first, count):
@@ -650,11 +652,14 @@ def main():
                           ("ONE state particle kept (SearchDDPM.single_state)" if single else "winner replicated to all N"),
                 "resample": f"ttc_ddim step (DDIM S1) with 'ps' scale 0.3, global multinomial resampling every "
                             f"{args.resample_every} steps"}[wl]
-        exchange = {"dps": "champion all-gather at the closing select (2 floats + 1 particle per rank)",
+        fetch = args.resample_fetch if args.resample_fetch != "auto" else ("selected" if world > 2 else "all")
+        exchange = {"dps": "ONE champion all-gather at the closing select (1 particle + its score and index per rank)",
                     "dps_scores": "RCCL all-gather of the [N/G] scores every step",
-                    "search": "per step: all-gather of one (min) + one champion particle per rank, device-side pick",
-                    "resample": f"every {args.resample_every} steps: all-gather of scores, identical host multinomial "
-                                f"draw, all-gather of states + HIP gather"}[wl]
+                    "search": "per step: ONE all-gather of one champion particle + its score per rank, device-side pick",
+                    "resample": f"every {args.resample_every} steps: all-gather of scores, identical device multinomial "
+                                f"draw on every rank, " + ("all-to-all of the drawn particles (each once per destination)"
+                                                           if fetch == "selected" else "all-gather of states") +
+                                " + HIP gather"}[wl]
         line = {
             "metric": "particles×denoise-steps/sec @256×256 N=64; x0_hat rel-L2 vs ref",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,

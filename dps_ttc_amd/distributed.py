@@ -297,13 +297,61 @@ def resample_ids(scores_local, temperature, generator, counts=None, return_score
     return (ids, all_scores) if return_scores else ids
 
 
-def resample_particles(particles_local, ids_global):
-    """Fetch the resampled particle set: all-gather of states, then a HIP gather of this rank's slots
-    (equal shards: every rank runs the same batch size)."""
+def fetch_plan(ids_global, n_local, rank, world):
+    """Who sends what for a resample with known ids (host int64 [world * n_local], identical on every rank).
+    Rank r's slots are ids[r*n_local:(r+1)*n_local]; particle g lives on rank g // n_local.  A source sends each particle
+    a destination asks for ONCE, however many of the destination's slots drew it (multinomial draws repeat the heavy
+    particles); the destination re-expands locally.
+    -> (send_local [int64: this rank's local particle indices, grouped by destination rank, ascending within a group],
+        in_splits [world], out_splits [world], slot_map [n_local int64: row of the receive buffer for each of my slots])."""
+    import numpy as np
+    ids = np.asarray(ids_global, dtype=np.int64).reshape(world, n_local)
+    if ids.size and (ids.min() < 0 or ids.max() >= world * n_local):
+        raise IndexError("resample id beyond the sharded particle set")
+    send, in_splits = [], []
+    for dst in range(world):                          # what I (as a source) send to dst
+        u = np.unique(ids[dst])
+        mine = u[(u >= rank * n_local) & (u < (rank + 1) * n_local)] - rank * n_local
+        send.append(mine)
+        in_splits.append(int(mine.size))
+    need = np.unique(ids[rank])                       # what I (as a destination) receive: sorted, hence grouped by source
+    owners = need // max(n_local, 1)
+    out_splits = [int((owners == src).sum()) for src in range(world)]
+    slot_map = np.searchsorted(need, ids[rank])
+    send_local = np.concatenate(send) if send else np.zeros(0, dtype=np.int64)
+    return send_local.astype(np.int64), in_splits, out_splits, slot_map.astype(np.int64)
+
+
+def resample_particles(particles_local, ids_global, fetch="auto"):
+    """Fetch the resampled particle set (equal shards: every rank runs the same batch size).
+    fetch="all":      all-gather of every rank's states, then a HIP gather of this rank's slots -- world x the bytes a
+                      rank needs, but no host knowledge of the ids (they may live on the device: no host read).
+    fetch="selected": only the particles each rank's slots drew travel, each once per destination (`fetch_plan`): ONE
+                      all-to-all with uneven splits straight over the pairwise xGMI links -- at most n_local particles
+                      received per rank instead of (world - 1) * n_local (N = 512 on 8 GPUs: <= 50 MB instead of 352 MB
+                      per rank and resample).  The split sizes are host integers, so device ids cost one host read.
+    fetch="auto":     "selected" when the ids are on the host already or there are more than two ranks, else "all"."""
     rank, world = _world()
     n_local = particles_local.shape[0]
+    if fetch not in ("auto", "all", "selected"):
+        raise ValueError("fetch: 'auto', 'all' or 'selected'")
+    if fetch == "auto":
+        fetch = "selected" if (not ids_global.is_cuda or world > 2) else "all"
     if _solo():
         pool = particles_local
+    elif fetch == "selected":
+        send_local, in_splits, out_splits, slot_map = fetch_plan(ids_global.cpu().numpy(), n_local, rank, world)
+        dev = particles_local.device
+        send_local, slot_map = torch.from_numpy(send_local), torch.from_numpy(slot_map)
+        if particles_local.is_cuda:
+            outbox = kernels.gather(particles_local, send_local.to(dev, non_blocking=True), validate=False)
+        else:
+            outbox = particles_local[send_local].contiguous()
+        inbox = torch.empty((sum(out_splits),) + tuple(particles_local.shape[1:]), dtype=outbox.dtype, device=dev)
+        dist.all_to_all_single(inbox, outbox, out_splits, in_splits)
+        if inbox.is_cuda:
+            return kernels.gather(inbox, slot_map.to(dev, non_blocking=True), validate=False)
+        return inbox[slot_map]
     else:
         pool = torch.empty((world * n_local,) + tuple(particles_local.shape[1:]), dtype=particles_local.dtype,
                            device=particles_local.device)
@@ -314,7 +362,7 @@ def resample_particles(particles_local, ids_global):
     return pool[mine]
 
 
-def global_resample(particles_local, scores_local, temperature, generator):
+def global_resample(particles_local, scores_local, temperature, generator, fetch="auto"):
     """The resampling block of TTC_DDIM.p_sample_loop (gaussian_diffusion.py:685-698) over a sharded particle set:
     -> (particles_local', scores_local', ids_global or None).  Same ids as one process holding all particles would
     draw from the same generator state.
@@ -323,7 +371,9 @@ def global_resample(particles_local, scores_local, temperature, generator):
     read of the gathered scores per resample -- the form the parity tests pin), or a DEVICE generator seeded identically
     on every rank: the draw then runs on the GPU as the reference's own does (its tensors live on cuda), every rank
     computes the same ids from the same gathered weights, and nothing is read on the host -- when all weights are equal
-    the draw is replaced by the identity on the device, as TTC_DDIM._resample does on one GPU."""
+    the draw is replaced by the identity on the device, as TTC_DDIM._resample does on one GPU.
+    fetch: how the drawn particles travel (`resample_particles`); with device ids "selected" costs the one host read of
+    the ids that "all" avoids, and moves world x fewer bytes -- "auto" takes it beyond two ranks."""
     rank, world = _world()
     n_local = particles_local.shape[0]
     if generator is not None and generator.device.type == "cuda" and particles_local.is_cuda:
@@ -333,13 +383,13 @@ def global_resample(particles_local, scores_local, temperature, generator):
         flat = w.max() == w.min()
         drawn = torch.multinomial(torch.where(flat, torch.ones_like(w), w), n, replacement=True, generator=generator)
         ids = torch.where(flat, torch.arange(n, device=w.device), drawn)
-        fetched = resample_particles(particles_local, ids)
+        fetched = resample_particles(particles_local, ids, fetch)
         mine = ids[rank * n_local:(rank + 1) * n_local]
         return fetched, kernels.gather(all_scores.reshape(n, 1), mine, validate=False).reshape(n_local), ids
     ids, all_scores = resample_ids(scores_local, temperature, generator, counts=[n_local] * world,
                                    return_scores=True)
     if ids is None:
         return particles_local, scores_local, None
-    fetched = resample_particles(particles_local, ids)
+    fetched = resample_particles(particles_local, ids, fetch)
     mine = ids[rank * n_local:(rank + 1) * n_local]
     return fetched, all_scores[mine].to(scores_local.device), ids

@@ -636,6 +636,9 @@ class TTC_DDIM(DDIM):
 
     global_resample = False
     resample_generator = None
+    #: how the drawn particles travel between ranks: "selected" (one all-to-all of the drawn ones, each once per
+    #: destination), "all" (all-gather of every state, no host read of device ids) or "auto" (distributed.resample_particles)
+    resample_fetch = "auto"
 
     def p_sample_loop(self, model, x_start, measurement, measurement_cond_fn, record, save_root, **kwargs):
         img = x_start.detach()
@@ -672,7 +675,8 @@ class TTC_DDIM(DDIM):
         n = len(distance)
         if self.global_resample:
             from . import distributed as dd
-            img, distance, ids = dd.global_resample(img, distance, resample_scale, self.resample_generator)
+            img, distance, ids = dd.global_resample(img, distance, resample_scale, self.resample_generator,
+                                                     fetch=self.resample_fetch)
             self.last_resample_ids = ids if ids is not None else self.last_resample_ids
             return img, distance
         if n <= 1:

@@ -46,8 +46,15 @@ def _worker(rank, world, port, q):
         # resampling: identical ids on every rank, states fetched from their owners
         ids = dd.resample_ids(mine_s, 100.0, torch.Generator().manual_seed(77))
         out["ids"] = ids.tolist()
-        fetched = dd.resample_particles(mine_p, ids)
-        out["fetch_ok"] = bool(all(torch.equal(fetched[i], particles[ids[rank * n_local + i]]) for i in range(n_local)))
+        out["fetch_ok"] = True
+        for mode in ("auto", "all", "selected"):      # both exchange forms fetch the same set
+            fetched = dd.resample_particles(mine_p, ids, fetch=mode)
+            out["fetch_ok"] &= bool(all(torch.equal(fetched[i], particles[ids[rank * n_local + i]]) for i in range(n_local)))
+        # one-sided draws: everything from rank 1 / everything from rank 0 / each rank keeps its own (nothing travels)
+        for forced in ([4, 4, 5, 3, 3, 4], [0, 0, 0, 2, 1, 0], [2, 1, 0, 5, 5, 3]):
+            fi = torch.tensor(forced)
+            fetched = dd.resample_particles(mine_p, fi, fetch="selected")
+            out["fetch_ok"] &= bool(torch.equal(fetched, particles[fi[rank * n_local:(rank + 1) * n_local]]))
         out["flat"] = dd.resample_ids(torch.ones(3), 100.0, torch.Generator().manual_seed(1)) is None
         # the sync-free select (what bench.py closes its timed region with): same winner, index as a tensor
         w2, b2 = dd.global_best_of_n_device(mine_s, mine_p, [3, 3])
@@ -98,6 +105,38 @@ def _worker(rank, world, port, q):
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
+
+
+def test_fetch_plan_is_consistent_across_ranks():
+    """distributed.fetch_plan (the selected-particles exchange of a resample): what rank s plans to send to rank d is what
+    rank d plans to receive from s, every particle travels at most once per destination, and expanding the receive buffer
+    by the slot map yields exactly the drawn set -- for worlds 1..8, skewed draws included."""
+    from dps_ttc_amd import distributed as dd
+    rng = np.random.default_rng(0)
+    for world, n_local in ((1, 5), (2, 3), (3, 4), (8, 64), (8, 1)):
+        n = world * n_local
+        for ids in (rng.integers(0, n, n), np.full(n, n - 1), np.arange(n), np.arange(n)[::-1].copy(),
+                    rng.choice([0, n // 2, n - 1], n)):
+            plans = [dd.fetch_plan(ids, n_local, r, world) for r in range(world)]
+            particles = rng.standard_normal((n, 2)).astype(np.float32)
+            moved = 0
+            for d in range(world):
+                send_d, in_d, out_d, slot_d = plans[d]
+                assert sum(in_d) == send_d.size and len(in_d) == len(out_d) == world
+                inbox = []
+                for s_ in range(world):
+                    send_s, in_s, _, _ = plans[s_]
+                    off = sum(in_s[:d])
+                    rows = send_s[off:off + in_s[d]]
+                    assert rows.size == out_d[s_]                          # the two sides agree on every split
+                    assert len(set(rows.tolist())) == rows.size            # once per destination
+                    inbox.append(particles[s_ * n_local + rows])
+                    moved += rows.size if s_ != d else 0
+                inbox = np.concatenate(inbox) if inbox else np.zeros((0, 2), np.float32)
+                np.testing.assert_array_equal(inbox[slot_d], particles[ids[d * n_local:(d + 1) * n_local]])
+            assert moved <= n                                             # never more than one set's worth in flight
+    with pytest.raises(IndexError):
+        dd.fetch_plan(np.array([0, 4, 1, 1]), 2, 0, 2)
 
 
 @pytest.mark.timeout(180)

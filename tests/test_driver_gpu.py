@@ -196,6 +196,9 @@ def test_bench_self_launch_two_ranks():
     ["--workload", "search", "--operator", "motion_blur", "--scaling", "strong", "--particles", "6"],
     # BASELINE configs[4]: phase retrieval, global resampling every 2 steps inside the timed region
     ["--workload", "resample", "--operator", "phase_retrieval", "--particles", "3", "--resample-every", "2"],
+    # the same with only the drawn particles travelling (one all-to-all with uneven splits)
+    ["--workload", "resample", "--operator", "phase_retrieval", "--particles", "3", "--resample-every", "2",
+     "--resample-fetch", "selected"],
 ])
 def test_bench_sharded_workloads_two_ranks(mode):
     """the timed search / resample / per-step-score modes of bench.py, two gloo ranks on this box's one GPU: the
@@ -215,6 +218,8 @@ def test_bench_sharded_workloads_two_ranks(mode):
     assert rec["scaling"] == ("strong" if "strong" in mode else "weak")
     assert rec["config"]["particles_per_gpu"] == 3 and rec["config"]["chains_per_gpu"] == 1
     assert 0 <= rec["best_of_n_index"] < 6 and "roofline" in rec
+    if "selected" in mode:
+        assert "all-to-all of the drawn particles" in rec["config"]["parallelism"]
 
 
 def test_bench_line_carries_both_schedules():
@@ -377,6 +382,13 @@ assert torch.equal(xr, x[ids]) and torch.equal(dr, (d * 40.0)[ids])
 gh = torch.Generator().manual_seed(1)
 xr, dr, ids = dd.global_resample(x, d * 40.0, 100.0, gh)
 assert ids is not None and torch.equal(xr, x[ids.to(dev)])
+for mode in ("all", "selected"):          # both exchange forms: all-gather of states / all-to-all of the drawn ones
+    g = torch.Generator(device=dev).manual_seed(2)
+    xr, dr, ids = dd.global_resample(x, d * 40.0, 100.0, g, fetch=mode)
+    assert torch.equal(xr, x[ids]) and torch.equal(dr, (d * 40.0)[ids])
+    assert torch.equal(dd.resample_particles(x, torch.tensor([5, 5, 5, 0, 5, 5]), fetch=mode), x[[5, 5, 5, 0, 5, 5]])
+w3, b3 = dd.global_best_of_n_device(d[:0], x[:0], [0])     # an empty shard still enters the exchange
+assert w3.shape == (1, 3, 64, 64)
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()
 assert float(t) == 1.5

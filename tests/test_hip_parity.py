@@ -533,6 +533,41 @@ def test_fused_step_full_size_per_particle_measurement(K, oracle, name):
                 per_particle_y=True, extra=True, finalize=True)
 
 
+@pytest.mark.parametrize("name,n", [("gauss", 512), ("phase", 512), ("motion", 256), ("sr4", 64), ("inpaint", 64)])
+def test_fused_step_full_batch_is_batch_independent(K, name, n):
+    """BASELINE's full particle counts (configs[2]: 64, configs[3]: 256, configs[4]: 512 -- here on ONE GPU, the
+    largest shard any configuration can hand a rank) through the size-independent property the domain offers: particles
+    are independent, so particle i of the N-particle launches equals, BIT FOR BIT, the same particle run alone or in a
+    small batch (x_{t-1}, norm, sample and clamp gate).  The small batches are what `test_fused_step_full_size` pins
+    against the oracle; this test carries that pin to the large grids (plane offsets beyond 2^31 bytes, thousands of
+    workgroups per launch, several generations of tiles)."""
+    hw = 256
+    gen = torch.Generator(device=DEV).manual_seed(100 + n)
+    mk = lambda *shape: torch.randn(*shape, device=DEV, generator=gen)
+    mask = (np.random.RandomState(9).rand(1, 1, hw, hw) < 0.5).astype(np.float32)
+    op, fkw = make_product_op(name, hw=hw, kernel=synthetic_motion_kernel(61, 4), mask=mask)
+    x, mo, z, gu = mk(n, 3, hw, hw), mk(n, 6, hw, hw) * 0.4, mk(n, 3, hw, hw), mk(n, 3, hw, hw) * 1e-2
+    y = op.forward(torch.rand(1, 3, hw, hw, device=DEV, generator=gen) * 2 - 1, **fkw).detach().contiguous()
+    ck = _sampler("ddpm", "").step_coefs[400]
+
+    def run(sl):
+        xs, ms, zs, gs = (t[sl].contiguous() for t in (x, mo, z, gu))
+        k = xs.shape[0]
+        handle = op.hip_handle_for(fkw["mask"]) if name == "inpaint" else op.hip_handle(xs)
+        buf = K.StepBuffers(handle, k, 3, hw, hw, DEV)
+        K.step_fwd(handle, buf, xs, ms, zs, y, ck)
+        K.step_bwd(handle, buf, y, 0.3, 1, ck)
+        out = K.step_update(buf, gs, ck)
+        return out.clone(), buf.norm.clone(), buf.sample.clone(), buf.inside.clone()
+
+    full = run(slice(0, n))
+    assert bool(torch.isfinite(full[0]).all()) and bool((full[1] > 0).all())
+    for sl in (slice(0, 1), slice(n - 1, n), slice(n // 2 - 1, n // 2 + 2), slice(n - 5, n)):
+        part = run(sl)
+        for a, b, what in zip(full, part, ("x_prev", "norm", "sample", "gate")):
+            assert torch.equal(a[sl], b), f"{name} N={n}: {what} of particles {sl} depends on the batch"
+
+
 # ----------------------------------------------------------------- conditioning per call (registry API, autograd path)
 @pytest.mark.parametrize("oname", ["gauss", "motion", "sr4", "inpaint", "phase"])
 @pytest.mark.parametrize("t", [900, 500, 0])

@@ -47,6 +47,12 @@ struct ResizeDev {
     // chip: 192 workgroups at N = 16, 256 x 256): chosen at launch, copied over ti / adj_rows / ablk_* / max_he
     int ti2, adj_rows2, max_he2;
     const int *ablk_lo2, *ablk_cnt2;
+    // a second, finer FORWARD blocking for the same case: tp2 = RT / out_w output rows per block (ONE trip of the H-pass
+    // loop) when tp = gparts * tp2, gparts in {2, 4}.  Both blockings leave the SAME partial sums behind -- one per tp2
+    // output rows, formed by the same threads in the same tree: a block of the coarse blocking publishes gparts of them
+    // -- so a particle's norm does not depend on how many particles were launched with it.  gparts = 1: no fine blocking.
+    int gparts, tp2, fwd_rows2;
+    const int *blk_lo2, *blk_cnt2, *own_lo2;
 };
 
 struct ResizeArgs {
@@ -77,7 +83,63 @@ __device__ __forceinline__ float norm_coef_r(float nv, float gn, int power)
     return power == 2 ? -2.0f * gn : (nv == 0.0f ? 0.0f : -gn / nv);
 }
 
-// LDS: s_in[fwd_rows][iws] | s_tmp[fwd_rows][out_w] | s_red[8]
+// block_sum of up to four values at once (same tree per value as common.h's block_sum: wave_sum, waves added in index
+// order); results valid in thread 0.  scratch: 16 floats (RT = 4 waves).
+__device__ __forceinline__ void block_sum4(float (&v)[4], float *scratch)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = wave_sum(v[g]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) scratch[g * 4 + wv] = v[g];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float t = 0.0f;
+            for (int i = 0; i < RT / 64; ++i) t += scratch[g * 4 + i];
+            v[g] = t;
+        }
+    }
+}
+
+// The H pass of one block and its partial sums.  gparts == 1: one partial per block (every trip of the loop accumulates
+// into one value per thread).  gparts > 1 (the block covers exactly gparts * RT outputs): trip j keeps its own value --
+// partial j of the block is what a block of the fine blocking, whose only trip it is, publishes as its one partial.
+template <bool RESID, typename F>
+__device__ __forceinline__ void resize_h_pass(const ResizeArgs &a, const ResizeDev &d, F &h_out, int total, int plane,
+                                              int nblk, int blk, float *s_red)
+{
+    if (d.gparts > 1) {                                          // launch-uniform
+        float sg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < d.gparts) sg[j] = h_out((int)threadIdx.x + j * RT, 0.0f);
+        if constexpr (RESID) {
+            block_sum4(sg, s_red);
+            if (threadIdx.x == 0) {
+                float *dst = &a.partials[((int64_t)plane * nblk + blk) * d.gparts];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < d.gparts) tail_publish(dst + j, sg[j], a.tail.counters != nullptr);
+            }
+            tail_arrive(a.tail, plane / a.c);
+        }
+        return;
+    }
+    float ss = 0.0f;
+    for (int it = threadIdx.x; it < total; it += RT) ss = h_out(it, ss);
+    if constexpr (RESID) {
+        const float t = block_sum(ss, s_red);
+        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t, a.tail.counters != nullptr);
+        tail_arrive(a.tail, plane / a.c);
+    }
+}
+
+// LDS: s_in[fwd_rows][iws] | s_tmp[fwd_rows][out_w] | s_red[16]
 // A staged row is stored RESIDUE-MAJOR: column j sits at word (j % 4) * q4 + j / 4 (q4 = ceil(in_w / 4), iws = 4 q4).
 // The W pass reads column ~(in_w / out_w) * o + const in lane o: in plain order that is a stride of 4 words for x4
 // (8-way bank conflict, 20 us of the 84 us launch at N = 64); residue-major, consecutive lanes read consecutive words.
@@ -206,8 +268,8 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
     }
     __syncthreads();
     // ---- stage C: H pass  out[p][o] = sum_k w_h[k,p] * tmp[i_h[k,p] - lo][o]
-    float ss = 0.0f;
-    for (int it = threadIdx.x; it < (p1 - p0) * d.out_w; it += RT) {
+    // one output element: the H pass, the store, and (RESID) the term it adds to the block's sum
+    auto h_out = [&](int it, float run) -> float {
         const int pl = it / d.out_w, p = p0 + pl, o = it % d.out_w;
         float acc = 0.0f;
         for (int k = 0; k < d.taps_h; ++k)
@@ -217,17 +279,14 @@ __global__ __launch_bounds__(RT) void k_resize_fwd(ResizeArgs a, ResizeDev d)
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
             const float r = yv - acc;
             if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
-            if constexpr (POST) ss = fmaf(r, r, ss);
-            else ss = a.l1 ? ss + fabsf(r) : fmaf(r, r, ss);
+            if constexpr (POST) return fmaf(r, r, run);
+            else return a.l1 ? run + fabsf(r) : fmaf(r, r, run);
         } else {
             a.out[(int64_t)plane * ohw + oo] = acc;
+            return 0.0f;
         }
-    }
-    if constexpr (RESID) {
-        const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t, a.tail.counters != nullptr);
-        tail_arrive(a.tail, plane / a.c);
-    }
+    };
+    resize_h_pass<RESID>(a, d, h_out, (p1 - p0) * d.out_w, plane, nblk, blk, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -356,8 +415,7 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
     }
     __syncthreads();
     // ---- H pass  out[p][o] = sum_k w_h[k,p] * tmp[i_h[k,p] - lo][o]   (as in k_resize_fwd)
-    float ss = 0.0f;
-    for (int it = threadIdx.x; it < (p1 - p0) * d.out_w; it += RT) {
+    auto h_out = [&](int it, float run) -> float {
         const int pl = it / d.out_w, p = p0 + pl, o = it % d.out_w;
         float acc = 0.0f;
         for (int k = 0; k < d.taps_h; ++k)
@@ -367,17 +425,14 @@ __global__ __launch_bounds__(RT, 3) void k_resize_fwd_rows(ResizeArgs a, ResizeD
             const float yv = a.y[((int64_t)(a.y_n == 1 ? 0 : n) * a.c + ch) * ohw + oo];
             const float r = yv - acc;
             if (a.out) a.out[(int64_t)plane * ohw + oo] = r;
-            if constexpr (POST) ss = fmaf(r, r, ss);
-            else ss = a.l1 ? ss + fabsf(r) : fmaf(r, r, ss);
+            if constexpr (POST) return fmaf(r, r, run);
+            else return a.l1 ? run + fabsf(r) : fmaf(r, r, run);
         } else {
             a.out[(int64_t)plane * ohw + oo] = acc;
+            return 0.0f;
         }
-    }
-    if constexpr (RESID) {
-        const float t = block_sum(ss, s_red);
-        if (threadIdx.x == 0) tail_publish(&a.partials[(int64_t)plane * nblk + blk], t, a.tail.counters != nullptr);
-        tail_arrive(a.tail, plane / a.c);
-    }
+    };
+    resize_h_pass<RESID>(a, d, h_out, (p1 - p0) * d.out_w, plane, nblk, blk, s_red);
 }
 
 // LDS: s_u[adj_rows][out_w] | s_t[ti][out_w]
@@ -628,12 +683,10 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
     }
 
     // ---- forward blocking: largest tp (<= 16) whose staged rows fit the LDS budget
-    int best_tp = 0;
-    std::vector<int> blo, bcnt, own;
-    for (int tp = 16; tp >= 1; tp >>= 1) {
+    auto fwd_blocking = [&](int tp, std::vector<int> &lo, std::vector<int> &cnt, std::vector<int> &ow_, int &maxrows) {
         const int nblk = (d.out_h + tp - 1) / tp;
-        std::vector<int> lo((size_t)nblk), cnt((size_t)nblk), ow_((size_t)nblk + 1);
-        int maxrows = 0;
+        lo.assign((size_t)nblk, 0); cnt.assign((size_t)nblk, 0); ow_.assign((size_t)nblk + 1, 0);
+        maxrows = 0;
         for (int b = 0; b <= nblk; ++b) ow_[(size_t)b] = (int)((int64_t)b * d.in_h / nblk);
         for (int b = 0; b < nblk; ++b) {
             int mn = ow_[(size_t)b], mx = ow_[(size_t)b + 1] - 1;  // staged range covers the owned rows too
@@ -647,15 +700,33 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
             cnt[(size_t)b] = mx - mn + 1;
             maxrows = std::max(maxrows, mx - mn + 1);
         }
-        const size_t lds = ((size_t)maxrows * ((d.in_w + 3) / 4 * 4 + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * tp)) * 4;
+        return ((size_t)maxrows * ((d.in_w + 3) / 4 * 4 + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * tp)) * 4;
+    };
+    int best_tp = 0;
+    std::vector<int> blo, bcnt, own;
+    for (int tp = 16; tp >= 1; tp >>= 1) {
+        int maxrows = 0;
+        const size_t lds = fwd_blocking(tp, blo, bcnt, own, maxrows);
         if (lds <= kLdsBudget || tp == 1) {
-            best_tp = tp; d.fwd_rows = maxrows; blo = lo; bcnt = cnt; own = ow_;
+            best_tp = tp; d.fwd_rows = maxrows;
             if (lds > 150 * 1024) { for (void *p : h->allocs) (void)hipFree(p); delete h; return DPSX_EUNSUPPORTED; }
             break;
         }
     }
     d.tp = best_tp;
     UP(blo, blk_lo) UP(bcnt, blk_cnt) UP(own, own_lo)
+    // the finer forward blocking (see ResizeDev): blocks of exactly RT outputs, when the coarse ones are 2 or 4 of them
+    d.gparts = 1; d.tp2 = d.tp; d.fwd_rows2 = d.fwd_rows; d.blk_lo2 = d.blk_lo; d.blk_cnt2 = d.blk_cnt; d.own_lo2 = d.own_lo;
+    if (RT % d.out_w == 0 && d.out_h % d.tp == 0) {
+        const int tp2 = RT / d.out_w;
+        if (tp2 >= 1 && d.tp % tp2 == 0 && (d.tp / tp2 == 2 || d.tp / tp2 == 4)) {
+            std::vector<int> blo2, bcnt2, own2;
+            int maxrows2 = 0;
+            (void)fwd_blocking(tp2, blo2, bcnt2, own2, maxrows2);        // fewer staged rows than the coarse one: fits
+            d.gparts = d.tp / tp2; d.tp2 = tp2; d.fwd_rows2 = maxrows2;
+            UP(blo2, blk_lo2) UP(bcnt2, blk_cnt2) UP(own2, own_lo2)
+        }
+    }
     // ---- adjoint blocking: the largest ti (<= ti_max) whose staged rows fit the LDS budget
     auto adj_blocking = [&](int ti_max, int &best_ti, int &rows, int &he, std::vector<int> &alo, std::vector<int> &acnt) {
         for (int ti = ti_max; ti >= 1; ti >>= 1) {
@@ -712,7 +783,27 @@ static const ResizeDev &dev_of(const dpsx_op *op) { return reinterpret_cast<cons
 int64_t resize_parts_per_particle(const dpsx_op *op, int64_t c)
 {
     const ResizeDev &d = dev_of(op);
-    return c * ((d.out_h + d.tp - 1) / d.tp);
+    return c * ((d.out_h + d.tp - 1) / d.tp) * d.gparts;        // the same slots under either forward blocking
+}
+
+// workgroups per particle of the forward launch for `planes` planes (the in-launch tail counts arrivals)
+static bool fwd_fine(const ResizeDev &d, int64_t planes)
+{
+    static const char *force = getenv("DPSX_RESIZE_FWD_BLOCKING");     // A/B switch for tools/kbench.py: coarse | fine
+    if (d.gparts == 1) return false;
+    if (force && force[0] == 'c') return false;
+    if (force && force[0] == 'f') return true;
+    // few planes: the coarse blocking would leave CUs without a workgroup (N = 16 at 256 x 256: 192 workgroups on 256
+    // CUs).  Measured on MI355X (tools/ab_resize_fwd.sh, x4 at 256 x 256, fused forward, coarse / fine in us): N = 16
+    // 22.0 / 20.4 (rocprof), N = 32 32.7 / 35.9, N = 40 45.0 / 44.3, N = 48 49.2 / 52.9 -- the fine blocks re-stage 1.75x
+    // the rows, which only pays while the coarse grid is smaller than the chip
+    return planes * (d.out_h / d.tp) <= 256;
+}
+
+static int64_t resize_fwd_blocks_per_particle(const dpsx_op *op, int64_t c, int64_t planes)
+{
+    const ResizeDev &d = dev_of(op);
+    return c * ((d.out_h + d.tp - 1) / d.tp) * (fwd_fine(d, planes) ? d.gparts : 1);
 }
 
 template <typename K>
@@ -738,7 +829,11 @@ static int allow_lds(K kernel, bool &done)
 template <bool POST, bool RESID>
 static int launch_fwd(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStream_t s)
 {
-    const ResizeDev &d = dev_of(op);
+    ResizeDev d = dev_of(op);
+    if (fwd_fine(d, a.planes)) {        // one partial per block, in the slots the coarse blocks would have filled
+        d.tp = d.tp2; d.fwd_rows = d.fwd_rows2; d.blk_lo = d.blk_lo2; d.blk_cnt = d.blk_cnt2; d.own_lo = d.own_lo2;
+        d.gparts = 1;
+    }
     const unsigned grid = (unsigned)(a.planes * ((d.out_h + d.tp - 1) / d.tp));
     const size_t lds = ((size_t)d.fwd_rows * ((d.in_w + 3) / 4 * 4 + d.out_w) + 32 + 2 * (size_t)(d.taps_w * d.out_w + d.taps_h * d.tp)) * 4;
     const int wu = d.in_w / 4;
@@ -800,7 +895,7 @@ int resize_step_fwd(const dpsx_op *op, const StepFwdArgs &f, hipStream_t s)
     a.inside_w = f.inside; a.y = f.y; a.y_n = (int)f.y_n; a.out = f.resid; a.partials = f.partials;
     a.c = (int)f.c; a.planes = (int)(f.n * f.c); a.k = f.k;
     a.tail = f.tail;
-    a.tail.blocks_per_particle = (int)resize_parts_per_particle(op, f.c);
+    a.tail.blocks_per_particle = (int)resize_fwd_blocks_per_particle(op, f.c, f.n * f.c);
     const bool vec = rz_vec(op, {f.x_t, f.model_out, f.noise, f.x0_hat, f.sample}) &&
                      (reinterpret_cast<uintptr_t>(f.inside) & 3u) == 0;
     return launch_fwd<true, true>(op, a, vec, s);
@@ -826,7 +921,7 @@ int resize_score(const dpsx_op *op, const float *x, const float *y, int64_t y_n,
     a.planes = (int)(n * c);
     a.l1 = l1;
     a.tail = tail;
-    a.tail.blocks_per_particle = (int)resize_parts_per_particle(op, c);
+    a.tail.blocks_per_particle = (int)resize_fwd_blocks_per_particle(op, c, n * c);
     return launch_fwd<false, true>(op, a, rz_vec(op, {x}), s);
 }
 

@@ -533,7 +533,7 @@ def test_fused_step_full_size_per_particle_measurement(K, oracle, name):
                 per_particle_y=True, extra=True, finalize=True)
 
 
-@pytest.mark.parametrize("name,n", [("gauss", 512), ("phase", 512), ("motion", 256), ("sr4", 64), ("inpaint", 64)])
+@pytest.mark.parametrize("name,n", [("gauss", 512), ("phase", 512), ("motion", 256), ("sr4", 64), ("sr8", 64), ("inpaint", 64)])
 def test_fused_step_full_batch_is_batch_independent(K, name, n):
     """BASELINE's full particle counts (configs[2]: 64, configs[3]: 256, configs[4]: 512 -- here on ONE GPU, the
     largest shard any configuration can hand a rank) through the size-independent property the domain offers: particles

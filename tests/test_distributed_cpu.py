@@ -107,6 +107,70 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dps_ttc_amd import distributed as dd
+        out = {}
+        n_local = 3
+        n = world * n_local
+        particles = torch.randn(n, 3, 4, 4, generator=torch.Generator().manual_seed(2))
+        scores = torch.tensor([9.0, 4.0, 7.0, 3.0, 8.0, 6.0, 5.0, 0.5, 2.0, 0.5, 1.0, 11.0])   # first minimum: 7 (rank 2)
+        lo, hi = dd.shard_range(n)
+        mine_p, mine_s = particles[lo:hi].clone(), scores[lo:hi].clone()
+        out["shard"] = (lo, hi)
+        w, b = dd.global_best_of_n_device(mine_s, mine_p, [n_local] * world)
+        out["dev"] = (int(b), bool(torch.equal(w[0], particles[7])))
+        sel = dd.GlobalSelect()(mine_s, mine_p)
+        out["select"] = bool(all(torch.equal(sel[i], particles[7]) for i in range(n_local)))
+        # uneven shards, one of them empty: counts [4, 0, 5, 3]
+        counts = [4, 0, 5, 3]
+        off = [0, 4, 4, 9]
+        up, us = particles[off[rank]:off[rank] + counts[rank]].clone(), scores[off[rank]:off[rank] + counts[rank]].clone()
+        w, b, alls = dd.global_best_of_n(us, up, counts)
+        out["uneven"] = (b, alls.tolist(), bool(torch.equal(w[0], particles[7])))
+        w, b = dd.global_best_of_n_device(us, up, counts)
+        out["uneven_dev"] = (int(b), bool(torch.equal(w[0], particles[7])))
+        # resampling over four ranks: both exchange forms fetch the set one process would hold
+        gen = torch.Generator().manual_seed(21)
+        xr, dr, ids = dd.global_resample(mine_p, mine_s * 60.0, 100.0, gen, fetch="selected")
+        out["ids"] = ids.tolist()
+        out["sel_ok"] = bool(torch.equal(xr, particles[ids[lo:hi]]) and torch.equal(dr, (scores * 60.0)[ids[lo:hi]]))
+        xa = dd.resample_particles(mine_p, ids, fetch="all")
+        out["all_ok"] = bool(torch.equal(xa, xr))
+        skew = torch.tensor([11] * 6 + [0] * 6)            # two particles feed everybody
+        out["skew_ok"] = bool(torch.equal(dd.resample_particles(mine_p, skew, fetch="selected"), particles[skew[lo:hi]]))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_4_gloo():
+    """four ranks (the CPU rehearsal of a wider node): rank-major shards, the champion exchange, uneven and empty shards,
+    and the resampling exchange in both forms -- all-gather of every state / one all-to-all of the drawn particles"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    scores = [9.0, 4.0, 7.0, 3.0, 8.0, 6.0, 5.0, 0.5, 2.0, 0.5, 1.0, 11.0]
+    w = torch.exp(-torch.tensor(scores) * 60.0 / 100.0)
+    ids1 = torch.multinomial(w, 12, replacement=True, generator=torch.Generator().manual_seed(21)).tolist()
+    for r in range(4):
+        assert res[r]["shard"] == (3 * r, 3 * r + 3)
+        assert res[r]["dev"] == (7, True) and res[r]["select"]
+        assert res[r]["uneven"] == (7, scores, True) and res[r]["uneven_dev"] == (7, True)
+        assert res[r]["ids"] == ids1                       # the draw one process holding all twelve would make
+        assert res[r]["sel_ok"] and res[r]["all_ok"] and res[r]["skew_ok"]
+
+
 def test_fetch_plan_is_consistent_across_ranks():
     """distributed.fetch_plan (the selected-particles exchange of a resample): what rank s plans to send to rank d is what
     rank d plans to receive from s, every particle travels at most once per destination, and expanding the receive buffer

@@ -55,7 +55,10 @@ def algo_p(operator, x0_store=True, workload="dps", semantic=False):
 
     "survey":   SURVEY.md 8d's compulsory traffic of the reference algorithm at the boundaries the UNet forces:
                 fwd = S1 6P + S2 (1 + rho)P, bwd = S3 (4 + rho)P, upd = S4 4P; inpainting recomputes r (rho -> 0);
-                phase retrieval stores the complex cotangent instead of r (S2 = 5.5P, S3 = 8.5P).
+                phase retrieval stores the complex cotangent instead of r (S2 = 5.5P, S3 = 8.5P).  This build's spectral
+                step forms the cotangent and runs the inverse column transforms inside the FORWARD launches (pass B:
+                the spectrum never goes back to HBM), so the 4.5P of S3 that are the cotangent's read are priced on the
+                launch that does that work: fwd 16P, bwd 4P -- the step's 24P are unchanged.
     "algorithmic": the same table for the configuration actually launched -- without the x0_hat store (the `ps` step
                 reads the image nowhere after K1) the forward half has no x0_hat write and the backward half no x0_hat
                 read (it works from the clamp gate): fwd - 1P, bwd - 1P.  `roofline.achieved` is priced on this.
@@ -63,7 +66,7 @@ def algo_p(operator, x0_store=True, workload="dps", semantic=False):
     are never written: DESIGN.md section 2); what they really move is the PMC figure (`traffic`, profiles/traffic.json)."""
     rho = RHO[operator]
     if operator == "phase_retrieval":
-        survey = {"fwd": 11.5, "bwd": 8.5, "upd": 4.0}
+        survey = {"fwd": 11.5 + 4.5, "bwd": 8.5 - 4.5, "upd": 4.0}
     else:
         survey = {"fwd": 7.0 + rho, "bwd": 4.0 + rho, "upd": 4.0}
     algo = dict(survey)

@@ -61,10 +61,12 @@ def main():
     torch.cuda.synchronize()
     ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
     if args.one:
-        algo = 8 * bench.P_BYTES * n
+        # priced on the bytes this form moves (3P per particle-step); the replicated form's 8P would read as more than the
+        # HBM peak at this step time, which says the form skips traffic, not that it streams faster than the memory
+        roof = 8000e9 / (8 * bench.P_BYTES)
         print(f"search step (one state particle) N={n} {args.operator}: avg {ts.mean():.1f} us  min {ts.min():.1f} us  "
-              f"{n / ts.mean() * 1e6:.0f} particle-steps/s  {algo / ts.mean() / 1e3:.0f} GB/s against the replicated "
-              f"form's 8P/particle ({3 * bench.P_BYTES * n / ts.mean() / 1e3:.0f} GB/s on the 3P it moves)")
+              f"{n / ts.mean() * 1e6:.0f} particle-steps/s ({n / ts.mean() * 1e6 / roof:.2f} of the replicated form's 8P "
+              f"roofline of {roof / 1e6:.2f} M/s)  {3 * bench.P_BYTES * n / ts.mean() / 1e3:.0f} GB/s on the 3P it moves")
         return
     # the launches one by one (each timed alone, back to back with itself)
     s0 = ring[0]

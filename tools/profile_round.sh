@@ -28,24 +28,7 @@ for spec in "motion_blur fwd" "motion_blur bwd" "phase_retrieval fwd" "phase_ret
   rm -rf $OUT/${TAG}_sq_$1_$2_a $OUT/${TAG}_sq_$1_$2_b $OUT/${TAG}_sq_$1_$2_a.err $OUT/${TAG}_sq_$1_$2_b.err
 done
 echo "[3] sq done"
-{
-  echo "# tools/kbench.py / tools/kbench_search.py on MI355X, N=64, 256x256, us per launch of the fused step (avg and min over 30)"
-  echo "# fwd / bwd as the loop launches them: x0_hat not written out (--no-x0); 'with x0_hat store' rows: the API default"
-  for op in gaussian_blur super_resolution inpainting motion_blur phase_retrieval; do
-    echo "== $op"
-    python3 tools/kbench.py --operator $op --only fwd,bwd,upd --no-x0 2>/dev/null
-  done
-  echo "== gaussian_blur with the x0_hat store"
-  python3 tools/kbench.py --operator gaussian_blur --only fwd,bwd 2>/dev/null
-  echo "== gaussian_blur sigma=5.0 (reach 20 px: the 5-tap-group bucket of the separable kernels)"
-  python3 tools/kbench.py --operator gaussian_blur --sigma 5.0 --only fwd,bwd,upd --no-x0 2>/dev/null
-  echo "== phase retrieval, the round-2 passes B and C (DPSX_PHASE_V1=1)"
-  DPSX_PHASE_V1=1 python3 tools/kbench.py --operator phase_retrieval --only fwd,bwd --no-x0 2>/dev/null
-  echo "== search_ddpm step, replicated form (dpsx_search_step_f32)"
-  for op in gaussian_blur super_resolution inpainting; do python3 tools/kbench_search.py --operator $op 2>/dev/null; done
-  echo "== search_ddpm step, ONE state particle (dpsx_search_step_one_f32: what SearchDDPM runs after its first select)"
-  for op in gaussian_blur super_resolution inpainting; do python3 tools/kbench_search.py --operator $op --one 2>/dev/null; done
-} > $OUT/${TAG}_operators_kbench.txt
+bash tools/kbench_all.sh > $OUT/${TAG}_operators_kbench.txt
 echo "[4] kbench done"
 $B --steps 200 --warmup 20 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
 $B --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1_20steps.json 2>> $OUT/${TAG}_bench_n1.err
@@ -62,6 +45,14 @@ $B --workload search --search-form replicated --steps 200 --warmup 20 > $OUT/${T
 DPSX_BENCH_BACKEND=gloo $B --gpus 2 --steps 50 --warmup 5 --particles 32 > $OUT/${TAG}_bench_2rank_gloo_rehearsal.json 2> $OUT/${TAG}_bench_2rank.err
 DPSX_BENCH_BACKEND=gloo $B --gpus 2 --steps 50 --warmup 5 --operator motion_blur --scaling strong --particles 64 --workload dps_scores --semantic > $OUT/${TAG}_bench_2rank_gloo_config4.json 2>> $OUT/${TAG}_bench_2rank.err
 DPSX_BENCH_BACKEND=gloo $B --gpus 2 --steps 50 --warmup 5 --operator phase_retrieval --workload resample --particles 32 > $OUT/${TAG}_bench_2rank_gloo_config5.json 2>> $OUT/${TAG}_bench_2rank.err
+# 6. the exchanges through the real backend: a process group of ONE rank over "nccl" (= RCCL) -- what this pool's one-GPU
+#    boxes can run of it -- per collective (tools/rccl_probe.py) and as whole sharded workloads; the un-gated real-UNet line
+$B --workload search --steps 200 --warmup 20 --force-process-group > $OUT/${TAG}_bench_search_single_rccl_x1.json 2>> $OUT/${TAG}_bench_n1.err
+$B --operator phase_retrieval --workload resample --steps 200 --warmup 20 --force-process-group > $OUT/${TAG}_bench_config5_shard_rccl_x1.json 2>> $OUT/${TAG}_bench_n1.err
+$B --operator phase_retrieval --workload resample --steps 200 --warmup 20 --force-process-group --resample-fetch selected > $OUT/${TAG}_bench_config5_shard_rccl_x1_selected.json 2>> $OUT/${TAG}_bench_n1.err
+$B --operator motion_blur --particles 32 --workload dps_scores --semantic --steps 200 --warmup 20 --force-process-group > $OUT/${TAG}_bench_config4_shard_rccl_x1.json 2>> $OUT/${TAG}_bench_n1.err
+python3 tools/rccl_probe.py > $OUT/${TAG}_rccl_one_rank_probe.txt 2> /dev/null
+python3 tools/e2e_unet.py > $OUT/${TAG}_e2e_unet.txt 2> /dev/null
 echo "[5] bench done"
 for f in $OUT/${TAG}_bench_*.json; do
   python3 -c "

@@ -383,8 +383,12 @@ def main():
     # ---- particle groups on streams: kernels.ParticleGroups, the object sampler.particle_groups / the driver's
     # --particle_groups run the fused loop with.  Per-particle results do not depend on the grouping
     # (tests/test_driver_gpu.py checks it bit for bit).  Workloads with an exchange every step run one chain.
-    # (small batches do not fill the chip even as one chain -- N = 16 is 768 tiles on 256 CUs -- and lose as groups)
-    default_chains = 1 if wl != "dps" or semantic or n < 48 else (2 if args.operator == "phase_retrieval" else 3)
+    # (N = 16 is 768 tiles on 256 CUs: one short generation of workgroups per launch, nothing for a second group to fill)
+    # measured on MI355X (tools/ab_chains.sh, profiles/r03_ab_chains.txt; us per step, chains 1 / 2 / 3 / 4): N = 64 Gaussian
+    # 127 / - / 117 / 133, motion 172 / - / 161 / 190; N = 32 Gaussian 74.9 / 65.7 / 66.6 / 86.9, motion 103.5 / 90.4 / 90.9 /
+    # 85.0, SR x4 70.6 / 62.1 / - / 85.9; N = 16 no gain (43 us either way).  Every group costs the host three launches of
+    # ~6.5 us per step: with k groups a step cannot be shorter than ~20 k us, which is the cliff at 4 groups and above
+    default_chains = 1 if wl != "dps" or semantic or n < 24 else (2 if args.operator == "phase_retrieval" or n < 48 else 3)
     nch = max(1, min(args.chains if args.chains > 0 else default_chains, n))
     if shared_gpu or wl in ("search", "resample", "dps_scores"):
         nch = 1         # rank processes time-slicing ONE GPU (gloo rehearsal): several queues per process make it crawl

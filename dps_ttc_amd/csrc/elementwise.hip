@@ -610,7 +610,11 @@ __global__ __launch_bounds__(kThreads) void k_pack_champion(const float *__restr
     __shared__ float s_bv;
     __shared__ int64_t s_bi;
     if (best_in) {
-        if (threadIdx.x == 0) { s_bi = best_in[0]; s_bv = val_in ? val_in[0] : costs[best_in[0]]; }
+        if (threadIdx.x == 0) {         // (an index outside [0, n) yields a NaN record, never an out-of-bounds read)
+            const int64_t bi = best_in[0];
+            s_bi = bi;
+            s_bv = val_in ? val_in[0] : ((bi >= 0 && bi < n) ? costs[bi] : __builtin_nanf(""));
+        }
     } else {
         ArgMin best{0.0f, -1};
         for (int64_t i = threadIdx.x; i < n; i += kThreads) {

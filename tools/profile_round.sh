@@ -4,7 +4,7 @@
 # 1. kernel-trace + stats of the SAME command as the headline bench (short run), split by grid size;
 # 2. HBM traffic of the three fused launches of EVERY operator from the L2 fabric counters, in separate --pmc passes
 #    (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, HBM section) -> <tag>_traffic.json;
-# 3. SQ counters of the motion-blur and phase-retrieval launches (what binds them);
+# 3. SQ counters of the motion-blur, phase-retrieval, super-resolution and Gaussian launches (what binds them);
 # 4. the per-launch micro-bench of every operator and the search step;
 # 5. bench lines: headline (grouped + one chain in one line), every operator, the configs' own N, the sharded workloads on
 #    one GPU, a 2-rank self-launched rehearsal (gloo on this box's one GPU).
@@ -22,7 +22,7 @@ rm -rf $OUT/${TAG}_stats
 echo "[1] stats done"
 bash tools/pmc_traffic.sh $TAG > $OUT/${TAG}_pmc_traffic.log 2>&1; echo "[2] traffic rc=$?"
 cp $OUT/${TAG}_traffic.json profiles/traffic.json 2>/dev/null     # (on the box only: the bench lines below read it)
-for spec in "motion_blur fwd" "motion_blur bwd" "phase_retrieval fwd" "phase_retrieval bwd"; do
+for spec in "motion_blur fwd" "motion_blur bwd" "phase_retrieval fwd" "phase_retrieval bwd" "super_resolution fwd" "super_resolution bwd" "gaussian_blur fwd" "gaussian_blur bwd"; do
   set -- $spec
   bash tools/pmc_sq.sh $1 $2 ${TAG}_sq_$1_$2 > /dev/null 2>&1
   rm -rf $OUT/${TAG}_sq_$1_$2_a $OUT/${TAG}_sq_$1_$2_b $OUT/${TAG}_sq_$1_$2_a.err $OUT/${TAG}_sq_$1_$2_b.err

@@ -1280,11 +1280,44 @@ static int launch_sep_adj(const BlurArgs &a, const SepTaps &t, int reach, hipStr
     DPSX_LAUNCH((k_blur_sep_adj<R4, EPI>), grid_blocks(a), lds, s, a, t, reach);
 }
 
+template <int R4, bool EPI>
+static int launch_sep_adj_sym(const BlurArgs &a, const SepTaps &t, hipStream_t s)
+{
+    const size_t lds = sep_lds_bytes(4 * R4, true);
+    DPSX_LAUNCH((k_blur_sep_adj_sym<R4, EPI>), grid_blocks(a), lds, s, a, t);
+}
+
+// symmetric taps on both axes (bitwise), whole tiles, two or more of them per axis, reach inside the image: the adjoint
+// without fold terms (k_blur_sep_adj_sym)
+static bool sep_adj_sym_ok(const dpsx_op *op, const BlurArgs &a)
+{
+    static const char *force = getenv("DPSX_SEP_ADJ");          // A/B switch for tools/kbench.py: "fold" = the general kernel
+    if (force && force[0] == 'f') return false;
+    const int rr = op->radius4;
+    if (a.h % TH != 0 || a.w % TW != 0 || a.tiles_x < 2 || a.tiles_y < 2 || rr + 1 >= a.h || rr + 1 >= a.w) return false;
+    for (int i = 0; i < rr; ++i)
+        if (op->sep.h[i] != op->sep.h[2 * rr - i] || op->sep.v[i] != op->sep.v[2 * rr - i]) return false;
+    return true;
+}
+
 template <bool EPI>
 static int dispatch_sep_adj(const dpsx_op *op, const BlurArgs &a, hipStream_t s)
 {
     SepTaps f{};  // adjoint of a correlation = correlation with the reversed taps
     const int rr = op->radius4;
+    if (sep_adj_sym_ok(op, a)) {
+        switch (rr / 4) {
+        case 1: return launch_sep_adj_sym<1, EPI>(a, op->sep, s);
+        case 2: return launch_sep_adj_sym<2, EPI>(a, op->sep, s);
+        case 3: return launch_sep_adj_sym<3, EPI>(a, op->sep, s);
+        case 4: return launch_sep_adj_sym<4, EPI>(a, op->sep, s);
+        case 5: return launch_sep_adj_sym<5, EPI>(a, op->sep, s);
+        case 6: return launch_sep_adj_sym<6, EPI>(a, op->sep, s);
+        case 7: return launch_sep_adj_sym<7, EPI>(a, op->sep, s);
+        case 8: return launch_sep_adj_sym<8, EPI>(a, op->sep, s);
+        }
+        return DPSX_EUNSUPPORTED;
+    }
     for (int i = 0; i <= 2 * rr; ++i) {
         f.h[i] = op->sep.h[2 * rr - i];
         f.v[i] = op->sep.v[2 * rr - i];

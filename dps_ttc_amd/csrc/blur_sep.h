@@ -793,3 +793,97 @@ __global__ __launch_bounds__(NT, sep_adj_waves_per_simd(R4)) void k_blur_sep_adj
         for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, h0 + 4 * rg + i, ox, acc[i], coef, EPI);
     }
 }
+
+// Adjoint for SYMMETRIC taps (k[d] = k[2RR - d] on both axes -- every Gaussian), regular geometry, two or more tiles per
+// axis: no fold terms at all.  With A = C R (R: reflection padding, C: the correlation), A^T = R^T C^T; for symmetric taps
+// the reflected contributions can be moved to the INPUT side:   A^T u = D C E u,   where E is the same reflection
+// extension the forward operator stages (u[-j] = u[j], u[n-1+j] = u[n-1-j]) with the image's own border sample doubled
+// (positions 0 and n-1 each stand for themselves and for their mirror image, which coincides with them), and D halves
+// the outputs at positions 0 and n-1 (whose own mirror term does not exist: M(0) = {0}).  Per axis, and the two axes
+// commute.  [for n - 1 > reach; checked against the dense matrix in tests/test_oracle_golden.py]  So the launch is the
+// FORWARD pipeline on the cotangent -- reflecting loader, plain passes -- plus a x2 on one staged row / column of the
+// border tiles and a x0.5 on their outermost outputs (both exact), instead of up to RR extra FMAs per border pixel and
+// axis under divergence: at 256 x 256, twelve of the sixteen tiles of a plane are border tiles.
+template <int R4, bool EPI>
+__global__ __launch_bounds__(NT, sep_adj_waves_per_simd(R4)) void k_blur_sep_adj_sym(BlurArgs a, SepTaps taps)
+{
+    constexpr int RR = 4 * R4;
+    using G = SepGeom<RR>;
+    extern __shared__ __align__(16) float lds[];
+    float *s = lds, *s_nrm = lds + G::RH * G::SW;
+    int plane, ty, tx;
+    if (!block_to_tile(a, plane, ty, tx)) return;
+    const int h0 = ty * TH, w0 = tx * TW;
+    float coef = 0.0f;
+    const bool norm_split = EPI && !a.norm_in && a.norm_parts <= 4 * kWave;
+    NormPartials np;
+    if constexpr (EPI) {
+        if (norm_split) np = particle_norm_issue(a.norm_partials, a.norm_parts, plane / a.c);
+        else if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm);
+    }
+    const int slot = sep_slot(), cg = slot & 15, rg = slot >> 4;
+    uchar4 gate[4];
+    if constexpr (EPI) {
+        const uint8_t *ip = a.inside_r + (int64_t)plane * a.h * a.w + (unsigned)((h0 + 4 * rg) * a.w + w0 + 4 * cg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gate[i] = *reinterpret_cast<const uchar4 *>(ip + (unsigned)(i * a.w));
+    }
+    load_region_reg<RR, false, true>(s, h0, w0, a, plane);
+    if constexpr (EPI) { if (norm_split) particle_norm_reduce(np, a.norm_parts, s_nrm); }
+    __syncthreads();
+    if constexpr (EPI) {
+        const float nv = a.norm_in ? a.norm_in[plane / a.c] : s_nrm[0];
+        coef = norm_coef_dev(nv, a.scale, a.power);
+        if (!a.norm_in && a.norm_out && threadIdx.x == 0 && ty == 0 && tx == 0 && plane % a.c == 0)
+            a.norm_out[plane / a.c] = nv;
+    }
+    // the image's own border row / column inside the staged region, doubled (block-uniform: border tiles only; a tile owns
+    // at most one border per axis -- two or more tiles per axis)
+    const int br = h0 == 0 ? RR : (h0 + TH == a.h ? RR + TH - 1 : -1);
+    const int bc = w0 == 0 ? RR : (w0 + TW == a.w ? RR + TW - 1 : -1);
+    if (br >= 0 || bc >= 0) {
+        const int t = threadIdx.x;
+        if (br >= 0 && t < G::RW) s[br * G::SW + t] *= (t == bc ? 4.0f : 2.0f);
+        if (bc >= 0 && t >= NT / 2 && t - NT / 2 < G::RH && t - NT / 2 != br) s[(t - NT / 2) * G::SW + bc] *= 2.0f;
+        __syncthreads();
+    }
+    hpass_inplace<RR, 0>(s, taps.h);
+    __syncthreads();
+    float acc[4][4];
+    vpass_regs<RR, 0>(s, acc, rg, cg, taps.v);
+    const int ox = w0 + 4 * cg, oy = h0 + 4 * rg;
+    if (br >= 0 || bc >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float fy = (oy + i == 0 || oy + i == a.h - 1) ? 0.5f : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] *= ((ox + e == 0 || ox + e == a.w - 1) ? 0.5f : 1.0f) * fy;
+        }
+    }
+    if constexpr (EPI) {
+        const unsigned hw = (unsigned)(a.h * a.w), o = (unsigned)(oy * a.w + ox);
+        const int n = plane / a.c, ch = plane % a.c;
+        float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * hw + o;
+        const float mb = -a.k.b;
+        float4 ex[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ex[i] = make_float4(0, 0, 0, 0);
+        if (a.g_extra) {            // block-uniform: the semantic term's cotangent on x0_hat rides the same gate
+            const float *ep = a.g_extra + (int64_t)plane * hw + o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[i] = *reinterpret_cast<const float4 *>(ep + (unsigned)(i * a.w));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 g;
+            g.x = gate[i].x ? mb * (coef * acc[i][0] + ex[i].x) : 0.0f;
+            g.y = gate[i].y ? mb * (coef * acc[i][1] + ex[i].y) : 0.0f;
+            g.z = gate[i].z ? mb * (coef * acc[i][2] + ex[i].z) : 0.0f;
+            g.w = gate[i].w ? mb * (coef * acc[i][3] + ex[i].w) : 0.0f;
+            *reinterpret_cast<float4 *>(gp + (unsigned)(i * a.w)) = g;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out_epilogue<true>(a, plane, oy + i, ox, acc[i], coef, false);
+    }
+}

@@ -118,6 +118,43 @@ def test_adjoint_identity(oracle, name):
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0)
 
 
+def test_symmetric_kernel_adjoint_is_forward_on_a_doubled_border(oracle):
+    """The identity k_blur_sep_adj_sym rests on (csrc/blur_sep.h): for symmetric taps, (C R)^T u = D C E u -- E the forward
+    operator's reflection extension with the image's own border sample doubled, D halving the outputs on the border --
+    against the dense matrix in one dimension, and against the oracle's adjoint of the BASELINE Gaussian (whose taps are
+    bitwise symmetric) in two."""
+    rng = np.random.default_rng(0)
+    for n, R in ((16, 3), (9, 4), (64, 12), (7, 5), (14, 12)):
+        half = rng.standard_normal(R + 1)
+        taps = np.concatenate([half[:0:-1], half])
+        refl = lambda p: -p if p < 0 else (2 * (n - 1) - p if p > n - 1 else p)
+        A = np.zeros((n, n))
+        for i in range(n):
+            for d in range(2 * R + 1):
+                A[i, refl(i + d - R)] += taps[d]
+        u = rng.standard_normal(n)
+        e = np.array([u[refl(q - R)] for q in range(n + 2 * R)])
+        e[R] *= 2
+        e[R + n - 1] *= 2
+        out = np.array([np.dot(taps, e[m:m + 2 * R + 1]) for m in range(n)])
+        out[0] *= 0.5
+        out[n - 1] *= 0.5
+        np.testing.assert_allclose(out, A.T @ u, rtol=0, atol=1e-12)
+    k2 = oracle.tables.gaussian_kernel2d(61, 3.0).astype(np.float32)
+    assert np.array_equal(k2, k2[::-1, :]) and np.array_equal(k2, k2[:, ::-1]) and np.array_equal(k2, k2.T)
+    op = oracle.make_operator("gaussian_blur", kernel_size=61, intensity=3.0)
+    u = rng.standard_normal((1, 2, 40, 56)).astype(np.float32)
+    e = np.pad(u, ((0, 0), (0, 0), (30, 30), (30, 30)), mode="reflect").astype(np.float64)
+    e[:, :, 30, :] *= 2; e[:, :, 30 + 39, :] *= 2; e[:, :, :, 30] *= 2; e[:, :, :, 30 + 55] *= 2
+    out = np.zeros((1, 2, 40, 56))
+    for dy in range(61):
+        for dx in range(61):
+            if k2[dy, dx] != 0:
+                out += float(k2[dy, dx]) * e[:, :, dy:dy + 40, dx:dx + 56]
+    out[:, :, 0, :] *= 0.5; out[:, :, -1, :] *= 0.5; out[:, :, :, 0] *= 0.5; out[:, :, :, -1] *= 0.5
+    assert rel_l2(out, op.adjoint(u, (40, 56))) < 1e-6
+
+
 # ----------------------------------------------------------------- conditioning per call
 def _cond_op(oracle, g, oname):
     if oname == "gauss":

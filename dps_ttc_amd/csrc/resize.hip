@@ -854,7 +854,9 @@ static int launch_adj(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
     ResizeDev d = dev_of(op);
     // few planes: the coarse blocking would leave most of the 256 CUs without a workgroup (N = 16 at 256 x 256: 192 of
     // them) -- take the fine one
-    if ((int64_t)a.planes * ((d.in_h + d.ti - 1) / d.ti) < 2 * 256 && d.ti2 < d.ti) {
+    static const char *force = getenv("DPSX_RESIZE_ADJ_BLOCKING");     // A/B switch for tools/kbench.py: coarse | fine
+    const bool fine = force ? force[0] == 'f' : (int64_t)a.planes * ((d.in_h + d.ti - 1) / d.ti) < 2 * 256;
+    if (fine && d.ti2 < d.ti) {
         d.ti = d.ti2; d.adj_rows = d.adj_rows2; d.max_he = d.max_he2; d.ablk_lo = d.ablk_lo2; d.ablk_cnt = d.ablk_cnt2;
     }
     const unsigned grid = (unsigned)(a.planes * ((d.in_h + d.ti - 1) / d.ti));

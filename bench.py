@@ -90,7 +90,7 @@ def algo_p(operator, x0_store=True, workload="dps", semantic=False):
 
 KERNELS = {
     "gaussian_blur": {"fwd": "S1 + A(x0_hat) + residual + norm partials (k_blur_sep_fwd<3,POST,RESID>)",
-                      "bwd": "A^T + clamp gate + -b*coef (k_blur_sep_adj<3,EPI>)"},
+                      "bwd": "A^T (symmetric taps: D C E, no fold terms) + clamp gate + -b*coef (k_blur_sep_adj_sym<3,EPI>)"},
     "motion_blur": {"fwd": "S1 + tap-list A(x0_hat) + residual + norm partials (k_blur_taps<POST,RESID>)",
                     "bwd": "tap-list A^T on the image domain: plain + mirrored windows in one scan, gate, -b*coef (k_blur_taps_adj<EPI>)"},
     "super_resolution": {"fwd": "S1 + resize W,H passes + residual + norm partials (k_resize_rows_fwd<POST,RESID>)",

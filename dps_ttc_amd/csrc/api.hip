@@ -759,7 +759,11 @@ int dpsx_search_step_one_f32(dpsx_op *op, const float *x_t, const float *model_o
     rc = posterior_fwd(x_t, model_out, noise, nullptr, sample, nullptr, n, chw, to_coefs(coefs_host), s, true);
     if (rc != DPSX_OK) return rc;
     if ((rc = score_launch(op, ws, sample, y, y_n, 0, parts, n, c, h, w, s)) != DPSX_OK) return rc;
-    rc = finalize_select(score_tail(ws, parts, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, chw), s);
+    const Tail tail = score_tail(ws, parts, 0, nullptr, POT_NONE, nullptr, costs, best_idx_dev, best_val_dev, n, chw);
+    static const bool unfused = getenv("DPSX_SEARCH_ONE_UNFUSED") != nullptr;       // A/B switch for tools/kbench_search.py
+    if (!unfused && x_next && chw % 4 == 0 && aligned16(sample) && aligned16(x_next))   // costs + select + the one copy: one launch
+        return finalize_select_copy(tail, sample, x_next, chw, s);
+    rc = finalize_select(tail, s);
     if (rc != DPSX_OK || !x_next) return rc;
     return gather_f32(sample, best_idx_dev, x_next, 1, n, chw, true, s);
 }

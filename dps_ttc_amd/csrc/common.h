@@ -491,6 +491,7 @@ int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipS
 // one small launch: per-particle values from the partials (t.partials / parts / mode / prev / potential -> raw_out, out)
 // and, if t.best_idx, the torch.argmin-order select over them (t.counters is not used)
 int finalize_select(const Tail &t, hipStream_t s);
+int finalize_select_copy(const Tail &t, const float *src, float *dst, int64_t chw, hipStream_t s);
 int norm_bwd(const float *r, const float *norm, const float *g_norm, int power, float *g_ax,
              int64_t n, int64_t m, hipStream_t s);
 // g_model_out[:, :c] = -b * (inside ? coef_p * g_x0 : 0),  g_x0 = A^T r

@@ -245,10 +245,14 @@ int finalize_norm(const float *partials, int parts, float *norm, int64_t n, hipS
 // Measured alternative (r02): finishing inside the scoring launch ("last block done", common.h: Tail) costs every short
 // scoring block two dependent memory round trips while it holds its LDS -- 42 us instead of ~25 us at N = 64.
 constexpr int kSelThreads = 1024;
-__global__ __launch_bounds__(kSelThreads) void k_finalize_select(Tail t)
+// the body of the finalisation + select; `writer`: this block stores the costs / the select's outputs (with several blocks
+// -- k_finalize_select_copy -- every block computes the same values in the same order and ONE of them stores).
+// -> the winner's index (block-uniform, valid in every thread), -1 when no select was asked for
+__device__ __forceinline__ int64_t finalize_select_body(const Tail &t, const bool writer)
 {
     __shared__ float s_v[kSelThreads / kWave];
     __shared__ int64_t s_i[kSelThreads / kWave];
+    __shared__ int64_t s_best;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = kSelThreads / kWave;
     ArgMin best{0.0f, -1};
     constexpr int B = 4;          // particles per wave in flight: their partial loads are issued together (one latency)
@@ -275,20 +279,20 @@ __global__ __launch_bounds__(kSelThreads) void k_finalize_select(Tail t)
             for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, kWave);
             float v = t.mode == TAIL_L1SQ ? (float)(a * a * (double)t.l1_scale) : (float)sqrt(a);
             if (lane == 0) {
-                if (t.raw_out) t.raw_out[p] = v;
+                if (t.raw_out && writer) t.raw_out[p] = v;
                 if (t.prev) {
                     const float q = t.prev[p];
                     if (t.potential == POT_MEAN) v = v + q;
                     else if (t.potential == POT_MIN) v = (v != v || q != q) ? __builtin_nanf("") : fminf(v, q);
                     else if (t.potential == POT_DIFF) v = v - q;
                 }
-                t.out[p] = v;
+                if (writer) t.out[p] = v;
                 const ArgMin c{v, p};
                 if (argmin_better(c, best)) best = c;
             }
         }
     }
-    if (!t.best_idx) return;
+    if (!t.best_idx) return -1;
     if (lane == 0) { s_v[wave] = best.v; s_i[wave] = best.i; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -296,15 +300,44 @@ __global__ __launch_bounds__(kSelThreads) void k_finalize_select(Tail t)
             const ArgMin c{s_v[w], s_i[w]};
             if (argmin_better(c, best)) best = c;
         }
-        *t.best_idx = best.i < 0 ? 0 : best.i;
-        if (t.best_val) *t.best_val = best.v;
+        s_best = best.i < 0 ? 0 : best.i;
+        if (writer) {
+            *t.best_idx = s_best;
+            if (t.best_val) *t.best_val = best.v;
+        }
     }
+    __syncthreads();
+    return s_best;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_finalize_select(Tail t)
+{
+    (void)finalize_select_body(t, true);
+}
+
+// the same + ONE copy of the winner (the single-state search step: dpsx_search_step_one_f32): every block of the copy
+// finishes the costs and the select for itself (n * parts floats from the L2 -- 12 KB at N = 64) and copies its slice;
+// one launch and one launch boundary less than finalisation + dpsx_replicate_f32(n_out = 1)
+__global__ __launch_bounds__(kSelThreads) void k_finalize_select_copy(Tail t, const float *__restrict__ src,
+                                                                      float *__restrict__ dst, int64_t chw4)
+{
+    const int64_t b = finalize_select_body(t, blockIdx.x == 0);
+    const int64_t i = (int64_t)blockIdx.x * kSelThreads + threadIdx.x;
+    if (i < chw4) reinterpret_cast<float4 *>(dst)[i] = (reinterpret_cast<const float4 *>(src) + b * chw4)[i];
 }
 
 int finalize_select(const Tail &t, hipStream_t s)
 {
     if (t.n == 0) return DPSX_OK;
     k_finalize_select<<<1, kSelThreads, 0, s>>>(t);
+    return check_launch();
+}
+
+int finalize_select_copy(const Tail &t, const float *src, float *dst, int64_t chw, hipStream_t s)
+{
+    if (t.n == 0) return DPSX_OK;
+    const int64_t chw4 = chw / 4;
+    k_finalize_select_copy<<<(unsigned)((chw4 + kSelThreads - 1) / kSelThreads), kSelThreads, 0, s>>>(t, src, dst, chw4);
     return check_launch();
 }
 

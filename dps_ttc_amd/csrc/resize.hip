@@ -43,6 +43,10 @@ struct ResizeDev {
     const int *ell_w_idx;     // [ell_w][in_w] output column (0 where padded)
     const float *ell_w_w;     // [ell_w][in_w] weight (0 where padded)
     int max_he;               // max H-inverse entries of one adjoint block
+    int no_ellh;              // A/B switch (DPSX_RESIZE_ADJ_CSR): keep the CSR form of the H pass
+    int ell_h;                // ELL width of the H inverse: max entries of one input row (same entry order as the CSR form)
+    const int *ell_h_idx;     // [ell_h][in_h] output row (the row's first entry where padded)
+    const float *ell_h_w;     // [ell_h][in_h] weight (0 where padded)
     // a second, finer adjoint blocking for small particle counts (planes x blocks of the first one would not fill the
     // chip: 192 workgroups at N = 16, 256 x 256): chosen at launch, copied over ti / adj_rows / ablk_* / max_he
     int ti2, adj_rows2, max_he2;
@@ -483,6 +487,30 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
             s_wv[i] = d.ell_w_w[i];
         }
     }
+    // H inverse of this block's rows: fixed-width (ELL) rows when they fit the CSR form's LDS slots -- [EH][ti] indices
+    // (rebased to the staged rows) and weights, ONE independent load per thread, no pointer chase
+    constexpr int EH = 4;
+    static_assert(EH * 64 <= RT, "one ELL-H entry per thread");
+    const int nrows = i1 - i0;
+    const bool ellh = d.ell_h <= EH && EH * d.ti <= d.max_he && EH * d.ti <= RT && !d.no_ellh;     // launch-uniform
+    if (ellh) {
+        const int t = threadIdx.x, kk = t / d.ti, r = t - kk * d.ti;
+        const bool live = kk < EH && r < nrows;
+        const int src = min(kk, d.ell_h - 1) * d.in_h + i0 + min(r, nrows - 1);
+        const int hi0 = d.ell_h_idx[src];
+        const float hv0 = d.ell_h_w[src];
+        if (u4) {
+            if (t < nu / 4) *reinterpret_cast<float4 *>(s_u + 4 * t) = ureg0;
+            if (t + RT < nu / 4) *reinterpret_cast<float4 *>(s_u + 4 * (t + RT)) = ureg1;
+            for (int u = 4 * UQ * RT + t; u < nu; u += RT) s_u[u] = up[u];
+        } else {
+            for (int u = t; u < nu; u += RT) s_u[u] = up[u];
+        }
+        if (live) {
+            s_hi[kk * d.ti + r] = max(hi0 - lo, 0);
+            s_hv[kk * d.ti + r] = kk < d.ell_h ? hv0 : 0.0f;
+        }
+    } else {
     const int he0 = d.inv_h_ptr[i0], he1 = d.inv_h_ptr[i1];
     {   // first RT entries of each table in one shot (registers), leftovers by the loops
         const int nhe = he1 - he0, t = threadIdx.x;
@@ -504,10 +532,26 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
             s_hv[i] = d.inv_h_w[he0 + i];
         }
     }
+    }
     float *s_nrm = reinterpret_cast<float *>(s_hi + d.max_he);
     if constexpr (EPI) { if (!a.norm_in) particle_norm_to_lds(a.norm_partials, a.norm_parts, plane / a.c, s_nrm); }
     __syncthreads();
     // H adjoint: T[i][o] = sum_{e in inv_h[i]} w_e * u[p_e][o]
+    if (ellh) {
+        // fixed entry count: the gathers of an item do not wait for a trip count, and items of successive trips overlap
+#pragma unroll 4
+        for (int it = threadIdx.x; it < nrows * d.out_w; it += RT) {
+            const int ii = it / d.out_w, o = it - ii * d.out_w;
+            float wq[EH];
+            int iq[EH];
+#pragma unroll
+            for (int k = 0; k < EH; ++k) { wq[k] = s_hv[k * d.ti + ii]; iq[k] = s_hi[k * d.ti + ii]; }
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < EH; ++k) acc = fmaf(wq[k], s_u[iq[k] * d.out_w + o], acc);    // CSR entry order: same bits
+            s_t[ii * d.out_w + o] = acc;
+        }
+    } else
     for (int it = threadIdx.x; it < (i1 - i0) * d.out_w; it += RT) {
         const int ii = it / d.out_w, o = it - ii * d.out_w;
         const int e0 = s_hp[ii], e1 = s_hp[ii + 1];
@@ -680,6 +724,23 @@ int resize_create(dpsx_op *op, const float *w_h, const int64_t *i_h, const float
             }
         d.ell_w = ell;
         UP(ei, ell_w_idx) UP(ew, ell_w_w)
+    }
+    {   // ELL copy of the H inverse (hp / hi / hw: CSR by input row): fixed-width rows let the adjoint's H pass run with a
+        // compile-time entry count -- no per-row trip counts, no dependent pointer loads at the head of every workgroup
+        int ell = 1;
+        for (int i = 0; i < d.in_h; ++i) ell = std::max(ell, hp[(size_t)i + 1] - hp[(size_t)i]);
+        std::vector<int> ei((size_t)ell * d.in_h, 0);
+        std::vector<float> ew((size_t)ell * d.in_h, 0.0f);
+        for (int i = 0; i < d.in_h; ++i) {
+            const int e0 = hp[(size_t)i], e1 = hp[(size_t)i + 1];
+            for (int k = 0; k < ell; ++k) {
+                const bool real = e0 + k < e1;
+                ei[(size_t)k * d.in_h + i] = real ? hi[(size_t)(e0 + k)] : (e1 > e0 ? hi[(size_t)e0] : -1);
+                ew[(size_t)k * d.in_h + i] = real ? hw[(size_t)(e0 + k)] : 0.0f;
+            }
+        }
+        d.ell_h = ell;
+        UP(ei, ell_h_idx) UP(ew, ell_h_w)
     }
 
     // ---- forward blocking: largest tp (<= 16) whose staged rows fit the LDS budget
@@ -855,6 +916,8 @@ static int launch_adj(const dpsx_op *op, const ResizeArgs &a, bool vec, hipStrea
     // few planes: the coarse blocking would leave most of the 256 CUs without a workgroup (N = 16 at 256 x 256: 192 of
     // them) -- take the fine one
     static const char *force = getenv("DPSX_RESIZE_ADJ_BLOCKING");     // A/B switch for tools/kbench.py: coarse | fine
+    static const bool csr = getenv("DPSX_RESIZE_ADJ_CSR") != nullptr;
+    d.no_ellh = csr ? 1 : 0;
     const bool fine = force ? force[0] == 'f' : (int64_t)a.planes * ((d.in_h + d.ti - 1) / d.ti) < 2 * 256;
     if (fine && d.ti2 < d.ti) {
         d.ti = d.ti2; d.adj_rows = d.adj_rows2; d.max_he = d.max_he2; d.ablk_lo = d.ablk_lo2; d.ablk_cnt = d.ablk_cnt2;

@@ -539,9 +539,13 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     // H adjoint: T[i][o] = sum_{e in inv_h[i]} w_e * u[p_e][o]
     if (ellh) {
         // fixed entry count: the gathers of an item do not wait for a trip count, and items of successive trips overlap
+        const bool inc = RT % d.out_w == 0;          // a lane keeps its column, its row advances by RT / out_w per trip
+        const int o_inc = threadIdx.x % d.out_w, dii_h = RT / d.out_w;
+        int ii_inc = threadIdx.x / d.out_w - dii_h;
 #pragma unroll 4
         for (int it = threadIdx.x; it < nrows * d.out_w; it += RT) {
-            const int ii = it / d.out_w, o = it - ii * d.out_w;
+            ii_inc += dii_h;
+            const int ii = inc ? ii_inc : it / d.out_w, o = inc ? o_inc : it - ii * d.out_w;
             float wq[EH];
             int iq[EH];
 #pragma unroll
@@ -572,8 +576,11 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
     const int wu = d.in_w / U;
     const int total = (i1 - i0) * wu;
     const float mb = -a.k.b;
-    auto unit = [&](const int it, const uchar4 gate4, const bool have_gate) {
-        const int ii = it / wu, j0 = (it - ii * wu) * U;
+    // plane bases once; a unit's offset inside the plane fits 32 bits
+    const uint8_t *ipb = EPI ? a.inside_r + (int64_t)plane * ihw : nullptr;
+    float *gpb = EPI ? a.g_model_out + ((int64_t)n * 2 * a.c + ch) * ihw : a.out + (int64_t)plane * ihw;
+    const float *epb = (EPI && a.g_extra) ? a.g_extra + (int64_t)plane * ihw : nullptr;
+    auto unit = [&](const int ii, const int j0, const uchar4 gate4, const bool have_gate) {
         float g[U];
         if (VEC && regtab) {
             if constexpr (VEC) {
@@ -597,11 +604,11 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
                 g[q] = acc;
             }
         }
-        const int64_t o = (int64_t)(i0 + ii) * d.in_w + j0;
+        const unsigned o = (unsigned)((i0 + ii) * d.in_w + j0);
         if constexpr (EPI) {
-            const uint8_t *ip = a.inside_r + (int64_t)plane * ihw + o;
-            float *gp = a.g_model_out + ((int64_t)n * 2 * a.c + ch) * ihw + o;
-            const float *ep = a.g_extra ? a.g_extra + (int64_t)plane * ihw + o : nullptr;
+            const uint8_t *ip = ipb + o;
+            float *gp = gpb + o;
+            const float *ep = epb ? epb + o : nullptr;
             if constexpr (VEC) {
                 const uchar4 in = have_gate ? gate4 : *reinterpret_cast<const uchar4 *>(ip);
                 float4 ex = make_float4(0, 0, 0, 0);
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
                 gp[0] = ip[0] ? mb * (coef * g[0] + (ep ? ep[0] : 0.0f)) : 0.0f;
             }
         } else {
-            float *gp = a.out + (int64_t)plane * ihw + o;
+            float *gp = gpb + o;
             if constexpr (VEC) *reinterpret_cast<float4 *>(gp) = make_float4(g[0], g[1], g[2], g[3]);
             else gp[0] = g[0];
         }
@@ -629,17 +636,32 @@ __global__ __launch_bounds__(RT) void k_resize_adj(ResizeArgs a, ResizeDev d)
         uchar4 gates[GP];
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
-            const int it = min((int)threadIdx.x + q * RT, total - 1);
-            const int ii = it / wu, j0 = (it - ii * wu) * U;
-            gates[q] = *reinterpret_cast<const uchar4 *>(a.inside_r + (int64_t)plane * ihw + (int64_t)(i0 + ii) * d.in_w + j0);
+            int ii, j0;
+            if (regtab) {       // (same incremental indices as the unit loop below)
+                const int ii0 = threadIdx.x / wu;
+                ii = min(ii0 + q * (RT / wu), i1 - i0 - 1);
+                j0 = (threadIdx.x - ii0 * wu) * U;
+            } else {
+                const int it = min((int)threadIdx.x + q * RT, total - 1);
+                ii = it / wu;
+                j0 = (it - ii * wu) * U;
+            }
+            gates[q] = *reinterpret_cast<const uchar4 *>(ipb + (unsigned)((i0 + ii) * d.in_w + j0));
         }
+        if (regtab) {           // RT % wu == 0: a lane keeps its column group, its row advances by RT / wu per unit -- no division
+            const int ii0 = threadIdx.x / wu, j0 = (threadIdx.x - ii0 * wu) * U, dii = RT / wu;
 #pragma unroll
-        for (int q = 0; q < GP; ++q) {
-            const int it = threadIdx.x + q * RT;
-            if (it < total) unit(it, gates[q], true);
+            for (int q = 0; q < GP; ++q)
+                if (ii0 + q * dii < i1 - i0) unit(ii0 + q * dii, j0, gates[q], true);
+        } else {
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int it = threadIdx.x + q * RT;
+                if (it < total) unit(it / wu, (it % wu) * U, gates[q], true);
+            }
         }
     } else {
-        for (int it = threadIdx.x; it < total; it += RT) unit(it, make_uchar4(0, 0, 0, 0), false);
+        for (int it = threadIdx.x; it < total; it += RT) unit(it / wu, (it % wu) * U, make_uchar4(0, 0, 0, 0), false);
     }
 }
 

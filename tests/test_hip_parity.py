@@ -255,6 +255,37 @@ def test_resize_non_square_vs_oracle(K, oracle, factor, shape):
     assert rel_l2(host(op.hip_handle().adjoint(dev(u), in_hw=shape)), orc.adjoint(u, shape)) < TOL
 
 
+@pytest.mark.parametrize("in_hw,out_hw,taps", [((40, 48), (12, 10), (6, 5)), ((64, 64), (9, 16), (11, 3)), ((30, 52), (30, 13), (2, 7))])
+def test_resize_arbitrary_tables_vs_dense(K, in_hw, out_hw, taps):
+    """dpsx_op_create_resize takes ANY (weight, index) tables, not only the bicubic ones of resizer.py:55-74: random weights,
+    random indices (repeats inside a column, input rows / columns that nothing reads, rows that more than four outputs read
+    -- the CSR form of the adjoint's H pass, the staged-rows forward) against the dense matrices, forward and adjoint."""
+    rng = np.random.RandomState(in_hw[0] + taps[0])
+    (ih, iw), (oh, ow), (th, tw_) = in_hw, out_hw, taps
+    w_h, w_w = rng.randn(th, oh).astype(np.float32), rng.randn(tw_, ow).astype(np.float32)
+    i_h, i_w = rng.randint(0, ih, (th, oh)), rng.randint(0, iw, (tw_, ow))
+    i_h[:, 0] = 3                                   # one input row read by every tap of an output: repeats
+    i_h[i_h == 5] = 6                               # an input row nothing reads
+    w_w[rng.rand(tw_, ow) < 0.2] = 0.0              # explicit zero weights
+    handle = K.OpHandle.resize(ih, iw, w_h, i_h, w_w, i_w, DEV)
+    Ah, Aw = np.zeros((oh, ih)), np.zeros((ow, iw))
+    for k in range(th):
+        for p in range(oh):
+            Ah[p, i_h[k, p]] += w_h[k, p]
+    for k in range(tw_):
+        for o in range(ow):
+            Aw[o, i_w[k, o]] += w_w[k, o]
+    x = rng.randn(5, ih, iw).astype(np.float32)
+    y = handle.forward(dev(x[:, None]))
+    ref = np.einsum("pi,nij,oj->npo", Ah, x.astype(np.float64), Aw)
+    assert tuple(y.shape) == (5, 1, oh, ow) and rel_l2(host(y)[:, 0], ref) < TOL
+    u = rng.randn(5, oh, ow).astype(np.float32)
+    g = handle.adjoint(dev(u[:, None]), in_hw=(ih, iw))
+    refg = np.einsum("pi,npo,oj->nij", Ah, u.astype(np.float64), Aw)
+    assert tuple(g.shape) == (5, 1, ih, iw) and rel_l2(host(g)[:, 0], refg) < TOL
+    assert np.array_equal(host(g)[:, 0, 5, :], np.zeros((5, iw), np.float32))     # the unread row gets an exact zero
+
+
 def test_inpainting_requires_mask():
     from dps_ttc_amd.measurements import get_operator
     op = get_operator("inpainting", device=DEV)

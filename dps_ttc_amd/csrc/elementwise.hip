@@ -449,6 +449,15 @@ int plain_update(const float *sample, const float *ga, const float *gb, float *o
     return check_launch();
 }
 
+// index of element i of a [C, H, W] particle in the [H, W] mask.  A 64-bit remainder by a run-time divisor is a software
+// routine of a hundred-odd instructions -- more than the rest of these kernels; particles below 2^32 elements (all of them)
+// take the 32-bit form.
+__device__ __forceinline__ int64_t mask_index(int64_t i, int64_t chw, int64_t hw)
+{
+    if (chw <= 0xffffffffll) return (int64_t)((unsigned)i % (unsigned)hw);      // launch-uniform
+    return i % hw;
+}
+
 // ===================================================================== inpainting fused step
 // fwd: S1 + r = y - mask*x0 (not stored) + norm partials.   bwd: recompute r from x0_hat.
 __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const float *__restrict__ mask,
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_fwd(StepFwdArgs a, const
             vv = *reinterpret_cast<const float4 *>(a.model_out + e + chw);
             zv = *reinterpret_cast<const float4 *>(a.noise + o);
         }
-        const float4 mv = *reinterpret_cast<const float4 *>(mask + (i % hw));
+        const float4 mv = *reinterpret_cast<const float4 *>(mask + mask_index(i, chw, hw));
         const float4 yv = *reinterpret_cast<const float4 *>(a.y + (a.y_n == 1 ? 0 : p) * chw + i);
         bool b0, b1, b2, b3;
         float4 x0, sm;
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_step_bwd(StepBwdArgs a, const
     const int64_t o = p * chw + i;
     const float coef = norm_coef(a.norm ? a.norm[p] : s_nrm[0], a.scale, a.power);  // cotangent on A x0 is coef * r
     const float4 x0 = *reinterpret_cast<const float4 *>(a.x0_hat + o);
-    const float4 mv = *reinterpret_cast<const float4 *>(mask + (i % hw));
+    const float4 mv = *reinterpret_cast<const float4 *>(mask + mask_index(i, chw, hw));
     const float4 yv = *reinterpret_cast<const float4 *>(a.y + (a.y_n == 1 ? 0 : p) * chw + i);
     const uchar4 in = *reinterpret_cast<const uchar4 *>(a.inside + o);
     float4 g;

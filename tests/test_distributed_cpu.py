@@ -171,6 +171,57 @@ def test_world_size_4_gloo():
         assert res[r]["sel_ok"] and res[r]["all_ok"] and res[r]["skew_ok"]
 
 
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dps_ttc_amd import distributed as dd
+        n_local = 4
+        n = world * n_local
+        g = torch.Generator().manual_seed(3)
+        particles = torch.randn(n, 3, 4, 4, generator=g)
+        scores = (torch.rand(n, generator=g) * 300.0).round()
+        scores[19] = scores.min() - 1.0                    # a unique winner, on rank 4
+        lo, hi = dd.shard_range(n)
+        mine_p, mine_s = particles[lo:hi].clone(), scores[lo:hi].clone()
+        out = {}
+        w, b = dd.global_best_of_n_device(mine_s, mine_p, [n_local] * world)
+        out["dev"] = (int(b), bool(torch.equal(w[0], particles[19])))
+        sel = dd.GlobalSelect()(mine_s, mine_p, n_out=2)
+        out["select"] = bool(sel.shape[0] == 2 and torch.equal(sel[0], particles[19]) and torch.equal(sel[1], particles[19]))
+        xr, dr, ids = dd.global_resample(mine_p, mine_s, 100.0, torch.Generator().manual_seed(5))      # fetch="auto": selected
+        out["ids"] = ids.tolist()
+        out["sel_ok"] = bool(torch.equal(xr, particles[ids[lo:hi]]) and torch.equal(dr, scores[ids[lo:hi]]))
+        out["all_ok"] = bool(torch.equal(dd.resample_particles(mine_p, ids, fetch="all"), xr))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_8_gloo():
+    """eight ranks on the CPU -- the node size the BASELINE configurations name: the champion exchange and the resampling
+    exchange (uneven all-to-all of the drawn particles against the all-gather of every state) agree with one process"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    torch.randn(32, 3, 4, 4, generator=g)
+    scores = (torch.rand(32, generator=g) * 300.0).round()
+    scores[19] = scores.min() - 1.0
+    ids1 = torch.multinomial(torch.exp(-scores / 100.0), 32, replacement=True, generator=torch.Generator().manual_seed(5)).tolist()
+    for r in range(8):
+        assert res[r]["dev"] == (19, True) and res[r]["select"]
+        assert res[r]["ids"] == ids1 and res[r]["sel_ok"] and res[r]["all_ok"]
+
+
 def test_fetch_plan_is_consistent_across_ranks():
     """distributed.fetch_plan (the selected-particles exchange of a resample): what rank s plans to send to rank d is what
     rank d plans to receive from s, every particle travels at most once per destination, and expanding the receive buffer
